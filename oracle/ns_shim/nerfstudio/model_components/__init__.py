@@ -1,0 +1,1 @@
+"""Import shim (test infrastructure only) — see oracle/README.md."""

@@ -1,0 +1,88 @@
+"""The CPU oracle (oracle/cpu_ref.py) against golden vectors captured from the REFERENCE's own
+modules (oracle/make_golden.py).  CPU only.  Tolerances: the oracle is a re-ordering-free
+restatement in the same torch ops, so fp32 agreement is expected at ~1e-6; discontinuous
+outputs (mask, median depth index) must match exactly on these fixtures."""
+import pytest
+import torch
+
+from oracle import cpu_ref
+from tests.helpers import field_spec_from_meta, load_golden, max_abs, model_spec_from_meta
+
+CASES = ["eval_l8_w32", "train_l8_w32", "eval_l4_w32", "eval_l6_w32_nomask", "eval_l8_w64_near0"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_get_outputs_matches_reference(name):
+    meta, g = load_golden(name)
+    fs, ms = field_spec_from_meta(meta), model_spec_from_meta(meta)
+    i = g["in"]
+    torch.manual_seed(0)
+    out = cpu_ref.get_outputs(g["param"], fs, ms, i["origins"], i["directions"], i["pixel_area"], i["nears"],
+                              i["fars"], training=meta["training"], jitter=g.get("jitter"))
+    ref = g["out"]
+    assert sorted(out.keys()) == sorted(ref.keys()) == meta["keys"]
+    assert torch.equal(out["mask"].to(torch.uint8), ref["mask"])
+    assert int(out["mask"].sum()) == meta["M"]
+    for k, v in ref.items():
+        if k == "mask":
+            continue
+        assert tuple(out[k].shape) == tuple(v.shape), k
+        err = max_abs(out[k].detach(), v)
+        tol = 2e-6 if not k.startswith("depth") else 1e-5
+        assert err <= tol, f"{name}:{k}: max abs err {err}"
+
+
+def test_nomask_case_takes_early_out():
+    meta, g = load_golden("eval_l6_w32_nomask")
+    assert meta["M"] == 0 and "depth_reflect_fine" not in g["out"]
+
+
+def test_units_contract():
+    _, g = load_golden("units")
+    c = g["contract"]
+    m, cov = cpu_ref.contract(c["mean"], c["cov"])
+    assert max_abs(m, c["out_mean"]) <= 1e-6
+    assert max_abs(cov, c["out_cov"]) <= 1e-6
+    assert float(m.norm(dim=-1).max()) < 2.0  # contraction maps into the radius-2 ball
+    assert float(torch.diagonal(cov, dim1=-2, dim2=-1).min()) >= 0.0
+
+
+def test_units_sh34():
+    _, g = load_golden("units")
+    s = g["sh"]
+    out = cpu_ref.integrated_sh(s["dirs"], s["roughness"])
+    assert out.shape[-1] == 34
+    assert max_abs(out, s["out"]) <= 2e-6
+
+
+def test_units_reciprocal_sampler():
+    _, g = load_golden("units")
+    r = g["recip"]
+    R = r["eval_starts"].shape[0]
+    nears, fars = torch.zeros(R, 1), torch.full((R, 1), 256.0)
+    _, eb = cpu_ref.spaced_bins("reciprocal", 0.25, nears, fars, 16, None)
+    assert max_abs(eb[:, :-1], r["eval_starts"]) <= 1e-5 and max_abs(eb[:, 1:], r["eval_ends"]) <= 2e-5
+    sb, eb = cpu_ref.spaced_bins("reciprocal", 0.25, nears, fars, 16, r["train_rand"])
+    assert max_abs(sb[:, :-1], r["train_spacing_starts"]) <= 1e-6
+    assert max_abs(eb[:, :-1], r["train_starts"]) <= 1e-5 and max_abs(eb[:, 1:], r["train_ends"]) <= 2e-5
+
+
+def test_units_inf_color_and_heads():
+    meta, g = load_golden("units")
+    fs = cpu_ref.FieldSpec(num_layers=meta["layers"], width=meta["width"])
+    P = g["param"]
+    out = cpu_ref.inf_color(P, fs, g["sh"]["dirs"], g["inf"]["sqradius"])
+    assert max_abs(out, g["inf"]["out"]) <= 2e-6
+    h = g["heads"]
+    pn = cpu_ref.pred_normals(P, h["emb"])
+    assert max_abs(pn, h["pred_normals"]) <= 1e-6
+    ndd = torch.sum(g["sh"]["dirs"] * pn, dim=-1, keepdim=True)
+    assert max_abs(ndd, h["n_dot_d"]) <= 1e-6
+    rs = torch.sigmoid(cpu_ref.head(P, "field_output_roughness", h["emb"]))
+    assert max_abs(rs, h["roughness_sigmoid"]) <= 1e-6
+
+
+def test_param_count_matches_reference_default():
+    fs = cpu_ref.FieldSpec()
+    P = cpu_ref.init_params(fs)
+    assert sum(v.numel() for v in P.values()) == 618513
