@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the reflect-sampling-nerf hot path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1], the configuration the metric is quoted on):
+    4096 rays x 128 samples, 8-layer 256-wide trunk, fp32, fused forward + composite of one
+    sampling level: uniform sampler -> fused field kernel (IPE, trunk, heads, SH, mid MLP, colour)
+    -> per-ray compositing (weights, RGB on white, accumulation, median depth).
+    Synthetic camera-shell rays, random-init weights, inputs resident in HBM.
+With --gpus N every rank renders its own 4096-ray batch (weak scaling; rays are independent, the forward
+path has no data-path collective -- the gradient all-reduce belongs to the training step).
+
+One JSON line is printed by rank 0 (contract in the task statement), including
+  roofline     -- the dominant kernel (rsn_field_kernel), MFMA-bound: algorithmic FLOP (1,230,592 per sample,
+                  SURVEY §8(d)) / its average duration, measured live with HIP events on its stream;
+  cpu_baseline -- the CPU oracle (oracle/cpu_ref.py, a port of the reference's PyTorch op sequence) timed on the
+                  host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FLOP_PER_SAMPLE = 1_230_592  # 2 x 615,296 MAC at W=256, L=8
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--workload", default="level", choices=["level", "get_outputs"],
+                    help="level = BASELINE configs[1] (default); get_outputs = full eval get_outputs "
+                         "(coarse+fine+reflect), reported for information")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle's single-level render on the host cores, bounded sample (cpu_rays x samples)."""
+    from oracle import cpu_ref
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    fs = cpu_ref.FieldSpec(num_layers=args.layers, width=args.width)
+    P = cpu_ref.init_params(fs, seed=0)
+    Rc = args.cpu_rays
+    o, d, pa = cpu_ref.synthetic_rays(Rc, seed=0)
+    nears, fars = torch.full((Rc, 1), 2.0), torch.full((Rc, 1), 6.0)
+    with torch.no_grad():
+        cpu_ref.render_level(P, fs, o, d, pa, nears, fars, args.samples)  # warm-up
+        times = []
+        t_end = time.time() + 20.0
+        while len(times) < 3 or (time.time() < t_end and len(times) < 10):
+            t0 = time.perf_counter()
+            cpu_ref.render_level(P, fs, o, d, pa, nears, fars, args.samples)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": Rc / med,
+        "unit": "rays/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{Rc} rays x {args.samples} samples, same field ({args.layers}x{args.width}) and level, "
+                  f"median of {len(times)} runs, oracle/cpu_ref.render_level (eager PyTorch fp32)",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    import reflect_sampling_nerf_amd as pkg
+    from oracle.cpu_ref import synthetic_rays  # input generator only (data, not arithmetic)
+    from reflect_sampling_nerf_amd import ops
+    from reflect_sampling_nerf_amd._abi import RSN_SPACING_UNIFORM
+
+    pkg.load_library()
+    torch.manual_seed(0)  # identical random-init weights on every rank (data parallel replicas)
+    R, S = args.rays, args.samples
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S, num_importance_samples=S,
+                                            base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    if args.workload == "get_outputs":
+        with torch.no_grad():
+            model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised
+    model.to(dev).eval()
+    fld = model.field
+    o, d, pa = synthetic_rays(R, seed=rank)  # each rank renders its own rays
+    o, d, pa = o.to(dev), d.to(dev), pa.reshape(R).to(dev)
+    nears = torch.full((R,), 2.0, device=dev)
+    fars = torch.full((R,), 6.0, device=dev)
+    rb = pkg.RayBundle(origins=o, directions=d, pixel_area=pa[:, None], nears=nears[:, None], fars=fars[:, None])
+    fld.packed_weights()
+    flags = ops.RSN_COMP_EVAL | ops.RSN_COMP_CLIP_RGB
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    state = {}
+
+    def step(i=None):
+        if args.workload == "get_outputs":
+            state["out"] = model(rb)
+            return
+        sb, eb = ops.sample_spaced(R, None, S, RSN_SPACING_UNIFORM, 1.0, nears, fars, None)
+        if i is not None:
+            ev[i][0].record()
+        lv = fld.evaluate_frustums(o, d, pa, eb, full=True)
+        if i is not None:
+            ev[i][1].record()
+        state["out"] = ops.composite(R, None, S, 1, flags, lv["sigma"], eb, lv["color"])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * R * args.steps / elapsed
+        line = {
+            "metric": "rays/sec (train step) at 4096 rays x 128 samples, 1/2/4/8 MI355X; PSNR vs ref",
+            "value": value,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[1]: %d rays x %d samples, %d-layer %d-wide MLP, fp32, fused forward + "
+                             "composite of one sampling level (eval)" % (R, S, args.layers, args.width))
+                if args.workload == "level" else
+                ("full eval get_outputs: %d rays x (%d coarse + %d fine + reflect %d + %d), %dx%d field" %
+                 (R, S, S, cfg.num_reflect_coarse_samples, cfg.num_reflect_importance_samples, args.layers,
+                  args.width)),
+                "rays_per_gpu": R,
+                "samples_per_ray": S,
+                "parallelism": "dp%d (independent ray batches, no data-path collective)" % world,
+                "weights": "random-init (nn.Linear default), seed 0",
+            },
+        }
+        if args.workload == "level":
+            kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            flop = FLOP_PER_SAMPLE * R * S if (args.layers, args.width) == (8, 256) else None
+            if flop is not None:
+                achieved = flop / (kms * 1e-3) / 1e12
+                line["roofline"] = {
+                    "kernel": "rsn_field_kernel<8>",
+                    "bound": "mfma",
+                    "achieved": achieved,
+                    "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "traffic": None,
+                    "kernel_ms": kms,
+                    "algorithmic_flop_per_launch": flop,
+                }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+/*
+ * rsn.h -- C ABI of librsn_hip.so: the MI355X (gfx950) implementation of the
+ * reflect-sampling-nerf ray-batch volume-rendering hot path.
+ *
+ * The reference (236088/reflect-sampling-nerf) is pure Python on PyTorch and has NO FFI for this
+ * path; its boundary is the Nerfstudio Model/Field plugin surface.  This header
+ * is the boundary the build introduces underneath that surface: each entry point below replaces a
+ * group of reference calls, cited as file:line relative to /root/reference/reflect_sampling_nerf/.
+ * The Python host mirror (reflect_sampling_nerf_amd/) binds these with ctypes; INTEGRATION.md shows
+ * the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer to fp32 (or int32) unless it says host;
+ *   - no allocation and no ownership transfer inside the library: the caller (torch) owns inputs,
+ *     outputs and workspaces;
+ *   - every call is asynchronous on the given hipStream_t (passed as void*), never synchronises
+ *     the host, and is re-entrant for distinct streams;
+ *   - return 0 on success, a negative rsn_status otherwise; rsn_last_error() gives the message
+ *     (thread-local);
+ *   - "n_dev": optional device pointer to an int32 ray count that overrides the host count at run
+ *     time (dynamic number M of reflected rays, no host sync); pass NULL to use the host count.
+ */
+#ifndef RSN_H
+#define RSN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSN_ABI_VERSION 1
+#define RSN_MAX_TRUNK_LAYERS 16
+#define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
+#define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
+#define RSN_SH_DIM 34      /* IntegratedSHEncoding.get_out_dim, reflect_sampling_nerf_components.py:49-50 */
+
+typedef enum rsn_status {
+  RSN_OK = 0,
+  RSN_ERR_INVALID_ARGUMENT = -1,
+  RSN_ERR_UNSUPPORTED = -2,
+  RSN_ERR_HIP = -3,
+  RSN_ERR_WORKSPACE = -4
+} rsn_status;
+
+typedef enum rsn_spacing { RSN_SPACING_UNIFORM = 0, RSN_SPACING_RECIPROCAL = 1 } rsn_spacing;
+
+/* Shape of the Field: constructor knobs of ReflectSamplingNeRFNerfField
+ * (reflect_sampling_nerf_field.py:36-47) plus the frequency table of the position encoding the
+ * model builds for it (reflect_sampling_nerf_model.py:98-100: 2**linspace(0,16,16), computed by the
+ * caller so that it is bit-identical to the host framework's table). */
+typedef struct rsn_field_desc {
+  int32_t num_layers;   /* trunk nn.Linear count (base_mlp_num_layers), 2..RSN_MAX_TRUNK_LAYERS */
+  int32_t width;        /* base_mlp_layer_width: 64, 128 or 256 */
+  int32_t skip_layer;   /* layer whose input is cat([encoding, x]) (4 when num_layers >= 6), or -1 */
+  int32_t mid_width;    /* head_mlp_layer_width: 128 */
+  float density_bias;   /* 0.5 */
+  float freqs[RSN_NUM_FREQS];
+} rsn_field_desc;
+
+/* Parameters in torch.nn.Linear layout: weight [out,in] row-major, bias [out]; names follow the
+ * reference Field's state_dict (reflect_sampling_nerf_field.py:54-86).  field_output_low (:67) is
+ * never evaluated by the model and is therefore absent. */
+typedef struct rsn_field_params {
+  const float* trunk_w[RSN_MAX_TRUNK_LAYERS]; /* mlp_base.layers.{i}.weight */
+  const float* trunk_b[RSN_MAX_TRUNK_LAYERS]; /* mlp_base.layers.{i}.bias   */
+  const float* density_w;    const float* density_b;    /* field_output_density.net    [1,W]      */
+  const float* normals_w;    const float* normals_b;    /* field_output_normals.net    [3,W]      */
+  const float* roughness_w;  const float* roughness_b;  /* field_output_roughness.net  [1,W]      */
+  const float* diff_w;       const float* diff_b;       /* field_output_diff.net       [3,W]      */
+  const float* tint_w;       const float* tint_b;       /* field_output_tint.net       [3,W]      */
+  const float* bottleneck_w; const float* bottleneck_b; /* field_output_bottleneck.net [W,W]      */
+  const float* mid_w;        const float* mid_b;        /* mlp_mid.layers.0            [mid,34+W] */
+  const float* rgb_w;        const float* rgb_b;        /* field_output_mid.net        [3,mid]    */
+} rsn_field_params;
+
+/* Per-sample outputs of one field evaluation; any pointer may be NULL (output skipped). */
+typedef struct rsn_field_outputs {
+  float* sigma;        /* [N]    softplus(raw + density_bias)         field.py:133-136 */
+  float* color;        /* [N,3]  diff + tint * mid                    model.py:175,209,310,336 */
+  float* pred_normals; /* [N,3]  get_pred_normals                     field.py:139-144 */
+  float* n_dot_d;      /* [N]    get_reflection's n.d                 field.py:203-204 */
+  float* diff;         /* [N,3]  get_diff                             field.py:176-180 */
+  float* tint;         /* [N,3]  get_tint                             field.py:182-186 */
+  float* roughness;    /* [N]    sigmoid(roughness head)              field.py:150-155 (default act) */
+  float* raw_density;  /* [N]    density head before bias/softplus    field.py:133-135 */
+} rsn_field_outputs;
+
+int rsn_abi_version(void);
+const char* rsn_last_error(void);
+
+/* ---- weights: nn.Linear layout -> MFMA fragment order ---------------------------------------
+ * The field kernels stream weights in the exact order the 32x32x2 f32 MFMA consumes them; this
+ * re-lays the Field's parameters into one flat buffer (done once per optimiser step). */
+size_t rsn_packed_weights_bytes(const rsn_field_desc* desc);
+int rsn_pack_weights(const rsn_field_desc* desc, const rsn_field_params* params, float* packed,
+                     size_t packed_bytes, void* stream);
+
+/* ---- samplers --------------------------------------------------------------------------------
+ * rsn_sample_spaced replaces UniformSampler / ReciprocalSampler.generate_ray_samples
+ * (reflect_sampling_nerf_model.py:148,292; reflect_sampling_nerf_components.py:14-36).
+ * t_rand: [R,S+1] uniform [0,1) stratified jitter (training) or NULL (eval).
+ * Outputs: spacing_bins [R,S+1] (normalised), euclid_bins [R,S+1] (ray parameter t). */
+int rsn_sample_spaced(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t spacing, float tan,
+                      const float* nears, const float* fars, const float* t_rand, float* spacing_bins,
+                      float* euclid_bins, void* stream);
+
+/* rsn_sample_pdf replaces PDFSampler.generate_ray_samples with include_original=False
+ * (reflect_sampling_nerf_model.py:110,112,182,317).  weights [R,S_in], spacing_bins_in [R,S_in+1],
+ * u_rand [R,S_out+1] or NULL.  S_in, S_out <= 1024. */
+int rsn_sample_pdf(int32_t n_rays, const int32_t* n_dev, int32_t s_in, int32_t s_out, int32_t spacing, float tan,
+                   float histogram_padding, const float* nears, const float* fars, const float* weights,
+                   const float* spacing_bins_in, const float* u_rand, float* spacing_bins_out,
+                   float* euclid_bins_out, void* stream);
+
+/* ---- the field (dominant kernel) -------------------------------------------------------------
+ * rsn_field_forward_frustum: for every sample of every ray: conical frustum -> Gaussian ->
+ * contraction -> integrated positional encoding -> trunk MLP -> heads -> SH-34 -> mid MLP ->
+ * colour.  Replaces get_blob + contract + get_density + get_pred_normals + get_reflection +
+ * get_diff + get_tint + get_roughness + get_mid for one sampling level
+ * (reflect_sampling_nerf_field.py:90-186; driven from reflect_sampling_nerf_model.py:151-175,
+ * 185-209,293-310,319-336).  N = n_rays * n_samples; sample i of ray r is point r*S+i. */
+int rsn_field_forward_frustum(const rsn_field_desc* desc, const float* packed, int32_t n_rays, const int32_t* n_dev,
+                              int32_t n_samples, const float* origins, const float* directions,
+                              const float* pixel_area, const float* euclid_bins, const rsn_field_outputs* out,
+                              void* stream);
+
+/* rsn_field_forward_inf: get_inf_color (reflect_sampling_nerf_field.py:190-201): mean = 2d,
+ * Sigma = 0.6*sqradius*(I - d d^T), no contraction, SH inputs zeroed; out_rgb [M,3]. */
+int rsn_field_forward_inf(const rsn_field_desc* desc, const float* packed, int32_t n_rays, const int32_t* n_dev,
+                          const float* directions, const float* sqradius, float* out_rgb, void* stream);
+
+/* rsn_field_forward_gaussians: granular Field API (get_density(mean, cov) + heads,
+ * reflect_sampling_nerf_field.py:122-186) on explicit, already contracted Gaussians:
+ * means [N,3], cov_diag [N,3] (NULL => plain sin/cos encoding), view_dirs [N,3] (NULL => SH zeroed),
+ * embedding [N,W] optional output (post-ReLU trunk output). */
+int rsn_field_forward_gaussians(const rsn_field_desc* desc, const float* packed, int32_t n_points,
+                                const float* means, const float* cov_diag, const float* view_dirs,
+                                const rsn_field_outputs* out, float* embedding, void* stream);
+
+/* ---- compositing ------------------------------------------------------------------------------
+ * rsn_composite: RaySamples.get_weights + RGB/Accumulation/Depth(median)/Normals/Semantic
+ * renderers for one level (reflect_sampling_nerf_model.py:154-156,176-177,188-190,210-227,
+ * 296-297,311,322-323,337,341).  One wavefront per ray, wave-level scan for the transmittance.
+ * background: 0 = none ("random"), 1 = white, 2 = per-ray tensor bg_rgb [R,3].
+ * flags: RSN_COMP_EVAL = RGBRenderer in eval mode (nan_to_num the colours, clamp composites to [0,1]);
+ *        RSN_COMP_CLIP_RGB = additionally apply the model's own torch.clip(rgb, 0, 1)
+ *        (reflect_sampling_nerf_model.py:177,211; not applied to the reflect composites, :311,337).
+ * Outputs (NULL = skip): weights [R,S], rgb [R,3], accumulation
+ * [R], depth [R]; surface attributes from the optional per-sample inputs: diff_out [R,3] (white
+ * background), tint_out [R,3] (no background), normals_out [R,3] (normalised, eps 1e-10),
+ * roughness_out [R]. */
+typedef struct rsn_composite_io {
+  const float* sigma;        /* [R,S] */
+  const float* euclid_bins;  /* [R,S+1] */
+  const float* color;        /* [R,S,3] */
+  const float* bg_rgb;       /* [R,3] or NULL */
+  const float* diff;         /* [R,S,3] or NULL */
+  const float* tint;         /* [R,S,3] or NULL */
+  const float* pred_normals; /* [R,S,3] or NULL */
+  const float* roughness;    /* [R,S] or NULL */
+  float* weights;
+  float* rgb;
+  float* accumulation;
+  float* depth;
+  float* diff_out;
+  float* tint_out;
+  float* normals_out;
+  float* roughness_out;
+} rsn_composite_io;
+
+#define RSN_COMP_EVAL 1
+#define RSN_COMP_CLIP_RGB 2
+int rsn_composite(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t background, int32_t flags,
+                  const rsn_composite_io* io, void* stream);
+
+/* ---- reflection rays --------------------------------------------------------------------------
+ * rsn_reflect_setup: reflect_sampling_nerf_model.py:222-229,240-241,267-289: n_dot_d, mask =
+ * (acc > 1e-2) & (n_dot_d < 0), stable compaction of the masked rays, secondary-ray origins /
+ * directions / sqradius / pixel_area / nears / fars, and the default reflect colour
+ * white*(1-acc) for every ray.  Outputs: mask [R] (uint8), n_masked (device int32), ray_index [R]
+ * (first M entries = original ray of compacted ray i), compacted [M,*] arrays, reflect_default [R,3]
+ * written to BOTH reflect_coarse and reflect_fine. */
+typedef struct rsn_reflect_io {
+  const float* origins;       /* [R,3] */
+  const float* directions;    /* [R,3] */
+  const float* accumulation;  /* [R]   accumulation_fine */
+  const float* depth;         /* [R]   depth_fine (median) */
+  const float* pred_normals;  /* [R,3] rendered, normalised */
+  const float* roughness;     /* [R]   rendered */
+  uint8_t* mask;              /* [R] */
+  int32_t* n_masked;          /* [1] */
+  int32_t* ray_index;         /* [R] */
+  float* n_dot_d;             /* [R] */
+  float* origins2;            /* [R,3] (first M valid) */
+  float* directions2;         /* [R,3] */
+  float* sqradius;            /* [R]   */
+  float* pixel_area2;         /* [R]   pi * sqradius */
+  float* nears2;              /* [R]   0 */
+  float* fars2;               /* [R]   reflect_far */
+  float* reflect_coarse;      /* [R,3] white*(1-acc) */
+  float* reflect_fine;        /* [R,3] white*(1-acc) */
+} rsn_reflect_io;
+
+int rsn_reflect_setup(int32_t n_rays, float reflect_far, const rsn_reflect_io* io, void* stream);
+
+/* rsn_reflect_combine: out[ray_index[i]] = clip(diff[ray_index[i]] + tint[ray_index[i]] * comp[i], 0, 1)
+ * for i < *n_masked (reflect_sampling_nerf_model.py:312-313,338-339). */
+int rsn_reflect_combine(int32_t n_rays_max, const int32_t* n_masked, const int32_t* ray_index, const float* diff,
+                        const float* tint, const float* comp, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSN_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of include/rsn.h (librsn_hip.so).
+
+There is NO fallback: if the library is missing or does not export the ABI of include/rsn.h the
+import of the product path raises.  Tensors are passed as raw device pointers (`tensor.data_ptr()`),
+the stream as `torch.cuda.current_stream().cuda_stream`; the library never allocates or synchronises.
+"""
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+RSN_ABI_VERSION = 1
+RSN_MAX_TRUNK_LAYERS = 16
+RSN_NUM_FREQS = 16
+RSN_SPACING_UNIFORM = 0
+RSN_SPACING_RECIPROCAL = 1
+
+_fp = C.c_void_p  # device float*
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [
+        ("num_layers", C.c_int32),
+        ("width", C.c_int32),
+        ("skip_layer", C.c_int32),
+        ("mid_width", C.c_int32),
+        ("density_bias", C.c_float),
+        ("freqs", C.c_float * RSN_NUM_FREQS),
+    ]
+
+
+class FieldParams(C.Structure):
+    _fields_ = [
+        ("trunk_w", _fp * RSN_MAX_TRUNK_LAYERS),
+        ("trunk_b", _fp * RSN_MAX_TRUNK_LAYERS),
+        ("density_w", _fp), ("density_b", _fp),
+        ("normals_w", _fp), ("normals_b", _fp),
+        ("roughness_w", _fp), ("roughness_b", _fp),
+        ("diff_w", _fp), ("diff_b", _fp),
+        ("tint_w", _fp), ("tint_b", _fp),
+        ("bottleneck_w", _fp), ("bottleneck_b", _fp),
+        ("mid_w", _fp), ("mid_b", _fp),
+        ("rgb_w", _fp), ("rgb_b", _fp),
+    ]
+
+
+class FieldOutputs(C.Structure):
+    _fields_ = [(n, _fp) for n in
+                ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density")]
+
+
+class CompositeIO(C.Structure):
+    _fields_ = [(n, _fp) for n in
+                ("sigma", "euclid_bins", "color", "bg_rgb", "diff", "tint", "pred_normals", "roughness",
+                 "weights", "rgb", "accumulation", "depth", "diff_out", "tint_out", "normals_out", "roughness_out")]
+
+
+class ReflectIO(C.Structure):
+    _fields_ = [(n, _fp) for n in
+                ("origins", "directions", "accumulation", "depth", "pred_normals", "roughness", "mask", "n_masked",
+                 "ray_index", "n_dot_d", "origins2", "directions2", "sqradius", "pixel_area2", "nears2", "fars2",
+                 "reflect_coarse", "reflect_fine")]
+
+
+_SIGNATURES = {
+    "rsn_abi_version": (C.c_int, []),
+    "rsn_last_error": (C.c_char_p, []),
+    "rsn_packed_weights_bytes": (C.c_size_t, [C.POINTER(FieldDesc)]),
+    "rsn_pack_weights": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), _fp, C.c_size_t, C.c_void_p]),
+    "rsn_sample_spaced": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_float, _fp, _fp, _fp, _fp, _fp,
+                                    C.c_void_p]),
+    "rsn_sample_pdf": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _fp, _fp,
+                                 _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_field_forward_frustum": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp,
+                                            _fp, C.POINTER(FieldOutputs), C.c_void_p]),
+    "rsn_field_forward_inf": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_field_forward_gaussians": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp,
+                                              C.POINTER(FieldOutputs), _fp, C.c_void_p]),
+    "rsn_composite": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CompositeIO),
+                                C.c_void_p]),
+    "rsn_reflect_setup": (C.c_int, [C.c_int32, C.c_float, C.POINTER(ReflectIO), C.c_void_p]),
+    "rsn_reflect_combine": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class RsnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Load librsn_hip.so and bind every symbol of include/rsn.h.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RsnError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or reflect_sampling_nerf_amd/_build.py). There is no CPU/eager fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RsnError(f"{path} does not export {name} (include/rsn.h)") from e
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.rsn_abi_version()
+    if ver != RSN_ABI_VERSION:
+        raise RsnError(f"ABI version mismatch: library {ver}, binding {RSN_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load_library().rsn_last_error()
+        raise RsnError(f"librsn_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,51 @@
+// Shared declarations of librsn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rsn.h"
+
+#define RSN_K_ENC_PAD 104  // 99 encoded inputs padded to 13 K-iterations of 8
+#define RSN_K_SH_PAD 40    // 34 SH inputs padded to 5 K-iterations of 8
+#define RSN_ENC_ITS (RSN_K_ENC_PAD / 8)
+#define RSN_SH_ITS (RSN_K_SH_PAD / 8)
+
+void rsn_set_error(const char* fmt, ...);
+
+#define RSN_REQUIRE(cond, code, ...)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      rsn_set_error(__VA_ARGS__);           \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+#define RSN_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      rsn_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RSN_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+// Offsets (in floats) of every packed segment inside the flat packed-weights buffer.
+// A weight segment with n_it K-iterations and nbo 32-row output blocks is laid out
+// [it][nb][lane(64)][4]: the float4 that lane (i = lane&31, h = lane>>5) feeds to the four
+// v_mfma_f32_32x32x2_f32 K-steps of iteration `it` for output block nb, i.e.
+// W[nb*32 + i][col(it*8 + 4h + s)], s = 0..3.
+struct RsnPackedLayout {
+  int nb;           // width / 32
+  int nbm;          // mid_width / 32
+  size_t w_x[RSN_MAX_TRUNK_LAYERS];   // x-part of layer l (l >= 1)
+  size_t w_enc0;                      // layer 0 (encoding input)
+  size_t w_enc_skip;                  // encoding part of the skip layer
+  size_t b[RSN_MAX_TRUNK_LAYERS];     // bias of layer l
+  size_t w_bh, b_bh;                  // bottleneck (nb blocks) + heads (1 block)
+  size_t w_mid_sh, w_mid_x, b_mid;    // mlp_mid: SH part, bottleneck part
+  size_t w_rgb, b_rgb;                // field_output_mid (rows 4..6 of one block)
+  size_t total;                       // floats
+};
+
+int rsn_compute_layout(const rsn_field_desc* desc, RsnPackedLayout* L);

@@ -1,0 +1,550 @@
+// rsn_field.hip -- the dominant kernel: fused per-sample field evaluation on gfx950.
+//
+// One wavefront owns a tile of 32 sample points for the whole network.  With
+// v_mfma_f32_32x32x2_f32 computing D[n][m] = sum_k W[n][k] * X[m][k] (A = weights, B = points) the
+// accumulator of lane (m = lane&31, h = lane>>5) holds, for ITS point m, output features
+// nb*32 + 8q + 4h + j (register 4q+j).  The K index of the next layer is a free permutation, and the
+// packed weights (rsn_pack.hip) are laid out so that K-iteration `it` (8 features) consumes from
+// lane (m,h) exactly features it*8 + 4h + {0..3}: the four registers that lane already holds.
+// So activations never cross lanes between layers: each lane parks its float4's in a wave-private
+// LDS slab X[it][lane] (ds_write_b128 / ds_read_b128, conflict-free, no barriers) purely so that the
+// K loop can index them dynamically.  Weights stream L2 -> VGPR as 1 KiB-contiguous
+// global_load_dwordx4 per (it, nb), double-buffered one K-iteration (2048 MFMA cycles) ahead.
+//
+// Roofline: MFMA-bound.  1,230,592 algorithmic FLOP per sample at W=256, L=8;
+// the padded instruction stream issues 9,808 MFMAs per 32-point tile vs 9,614 algorithmic.
+//
+// Reference semantics restated here: reflect_sampling_nerf_field.py:90-207,
+// reflect_sampling_nerf_components.py:52-140 and the nerfstudio primitives N1-N3, N6.
+#include "rsn_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RSN_MODE_FRUSTUM 0
+#define RSN_MODE_INF 1
+#define RSN_MODE_GAUSS 2
+
+struct FieldArgs {
+  const float* packed;
+  RsnPackedLayout L;
+  int num_layers, skip_layer, width;
+  float density_bias;
+  float freqs[RSN_NUM_FREQS];
+  int mode;
+  int n_rays;          // rays (frustum / inf) or points (gauss)
+  const int* n_dev;    // optional device-side ray count
+  int S;               // samples per ray (1 for inf / gauss)
+  const float* origins;
+  const float* directions;
+  const float* pixel_area;
+  const float* bins;
+  const float* sqradius;
+  const float* means;
+  const float* cov_diag;
+  const float* view_dirs;
+  rsn_field_outputs out;
+  float* embedding;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small math, written to follow the torch op order of the reference (contraction off: -ffp-contract=off)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Conical frustum -> Gaussian (nerfstudio conical_frustum_to_gaussian / compute_3d_gaussian, N3),
+// followed by the reference's contraction (reflect_sampling_nerf_field.py:98-119).  Only the diagonal
+// of J Sigma J is consumed downstream (N2), so only that is formed.
+__device__ __forceinline__ void frustum_to_contracted(const float o[3], const float d[3], float pa, float t0, float t1,
+                                                      float mean_c[3], float var_c[3]) {
+  const float radius = sqrtf(pa) / 1.7724538509055159f;
+  const float mu = (t0 + t1) / 2.0f;
+  const float hw = (t1 - t0) / 2.0f;
+  const float hw2 = hw * hw, mu2 = mu * mu;
+  const float den = 3.0f * mu2 + hw2;
+  const float tmean = mu + (2.0f * mu * hw2) / den;
+  float mean[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) mean[c] = o[c] + d[c] * tmean;
+  const float hw4 = hw2 * hw2;
+  const float var_t = hw2 / 3.0f - 0.26666666666666666f * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+  const float var_r =
+      (radius * radius) * (mu2 / 4.0f + 0.4166666666666667f * hw2 - (0.26666666666666666f * hw4) / den);
+  const float dmag = fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f);
+  // Sigma = var_t d d^T + var_r (I - d (d/dmag)^T)
+  float S[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      S[i][j] = var_t * (d[i] * d[j]) + var_r * ((i == j ? 1.0f : 0.0f) - d[i] * (d[j] / dmag));
+  // contraction
+  const float n2 = mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2];
+  const float n = sqrtf(n2);
+  if (n > 1.0f) {
+    const float sc = (2.0f * n - 1.0f) / n2;
+    float J[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float eye = (i == j) ? 1.0f : 0.0f;
+        const float outer = mean[i] * mean[j] / n2;
+        J[i][j] = ((2.0f * n - 2.0f) * (eye - outer) + eye) / n2;
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mean_c[c] = sc * mean[c];
+    // diag(J S J)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const float js = J[i][0] * S[0][b] + J[i][1] * S[1][b] + J[i][2] * S[2][b];
+        acc += js * J[b][i];
+      }
+      var_c[i] = fmaxf(acc, 0.0f);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mean_c[c] = mean[c];
+      var_c[c] = fmaxf(S[c][c], 0.0f);
+    }
+  }
+}
+
+// 34 real-SH polynomial terms, bands l = 1, 2, 4, 8 (reflect_sampling_nerf_components.py:65-127), then the
+// per-band roughness attenuation exp(-rho*{1,3,10,36}) (components.py:136-139).
+__device__ __forceinline__ void sh34_attenuated(float x, float y, float z, float rho, float sh[34]) {
+  const float x2 = x * x, y2 = y * y, z2 = z * z;
+  const float xy = x * y, xz = x * z, yz = y * z;
+  const float a = x2 - y2;
+  const float p = 3.0f * x2 - y2;
+  const float q = x2 - 3.0f * y2;
+  const float z4 = z2 * z2, x4 = x2 * x2, y4 = y2 * y2;
+  const float im5 = y4 - 10.0f * x2 * y2 + 5.0f * x4;
+  const float re5 = x4 - 10.0f * x2 * y2 + 5.0f * y4;
+  const float im7 = (x2 - 5.0f * y2) * 7.0f * x4 + (21.0f * x2 - y2) * y4;
+  const float re7 = (x2 - 21.0f * y2) * x4 + (5.0f * x2 - y2) * 7.0f * y4;
+  const float re4 = x2 * q - y2 * p;
+  const float t6 = 143.0f * z4 * z2 - 143.0f * z4 + 33.0f * z2 - 1.0f;
+  const float t7 = 715.0f * z4 * z2 - 1001.0f * z4 + 385.0f * z2 - 35.0f;
+  const float t5 = 39.0f * z4 - 26.0f * z2 + 3.0f;
+  const float t4 = 65.0f * z4 - 26.0f * z2 + 1.0f;
+  const float e1 = expf(-rho), e2 = expf(-rho * 3.0f), e4 = expf(-rho * 10.0f), e8 = expf(-rho * 36.0f);
+  sh[0] = 0.48860251190291992f * y * e1;
+  sh[1] = 0.48860251190291992f * z * e1;
+  sh[2] = 0.48860251190291992f * x * e1;
+  sh[3] = 1.09254843059207907f * xy * e2;
+  sh[4] = 1.09254843059207907f * yz * e2;
+  sh[5] = 0.31539156525252001f * (3.0f * z2 - 1.0f) * e2;
+  sh[6] = 1.09254843059207907f * xz * e2;
+  sh[7] = 0.54627421529603953f * a * e2;
+  sh[8] = 2.50334294179670453f * xy * a * e4;
+  sh[9] = 1.77013076977993053f * yz * p * e4;
+  sh[10] = 0.94617469575756001f * xy * (7.0f * z2 - 1.0f) * e4;
+  sh[11] = 0.66904654355728916f * yz * (7.0f * z2 - 3.0f) * e4;
+  sh[12] = 0.1057855469152043038f * (35.0f * z4 - 30.0f * z2 + 3.0f) * e4;
+  sh[13] = 0.66904654355728916f * xz * (7.0f * z2 - 3.0f) * e4;
+  sh[14] = 0.473087347878780009f * a * (7.0f * z2 - 1.0f) * e4;
+  sh[15] = 1.77013076977993053f * xz * q * e4;
+  sh[16] = 0.62583573544917613f * re4 * e4;
+  sh[17] = 5.83141328139863895f * xy * (x2 * x4 - 7.0f * x4 * y2 + 7.0f * x2 * y4 - y2 * y4) * e8;
+  sh[18] = 5.83141328139863895f * yz * im7 * e8;
+  sh[19] = 1.06466553211908514f * xy * (15.0f * z2 - 1.0f) * (3.0f * x4 - 10.0f * x2 * y2 + 3.0f * y4) * e8;
+  sh[20] = 3.44991062209810801f * yz * (5.0f * z2 - 1.0f) * im5 * e8;
+  sh[21] = 1.91366609903732278f * xy * t4 * a * e8;
+  sh[22] = 1.23526615529554407f * yz * t5 * p * e8;
+  sh[23] = 0.91230451686981894f * xy * t6 * e8;
+  sh[24] = 0.1090412458987799555f * yz * t7 * e8;
+  sh[25] = 0.0090867704915649962938f *
+           (6435.0f * z4 * z4 - 12012.0f * z4 * z2 + 6930.0f * z4 - 1260.0f * z2 + 35.0f) * e8;
+  sh[26] = 0.1090412458987799555f * xz * t7 * e8;
+  sh[27] = 0.456152258434909470f * t6 * a * e8;
+  sh[28] = 1.23526615529554407f * xz * t5 * q * e8;
+  sh[29] = 0.478416524759330697f * t4 * re4 * e8;
+  sh[30] = 3.44991062209810801f * xz * (5.0f * z2 - 1.0f) * re5 * e8;
+  sh[31] = 0.53233276605954257f * (15.0f * z2 - 1.0f) * (x2 * re5 - y2 * im5) * e8;
+  sh[32] = 5.83141328139863895f * xz * re7 * e8;
+  sh[33] = 0.72892666017482986f * (x2 * re7 - y2 * im7) * e8;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA K loop: acc[nb] += W_seg[nb-block] * X, weights double-buffered in registers.
+// ------------------------------------------------------------------------------------------------
+template <int NBO>
+__device__ __forceinline__ void load_w(float4 (&w)[NBO], const float4* __restrict__ wp, int it) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) w[nb] = wp[(it * NBO + nb) * 64];
+}
+
+template <int NBO>
+__device__ __forceinline__ void mma4(f32x16 (&acc)[NBO], const float4 (&w)[NBO], const float4 b) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb].x, b.x, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb].y, b.y, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb].z, b.z, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb].w, b.w, acc[nb], 0, 0, 0);
+}
+
+// wseg: packed segment base (global), xl: this lane's slot of the LDS slab (float4 units, stride 64 per it).
+template <int NBO>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl, int n_it,
+                                     int lane) {
+  const float4* __restrict__ wp = reinterpret_cast<const float4*>(wseg) + lane;
+  float4 wa[NBO], wb[NBO];
+  float4 ba, bb;
+  load_w<NBO>(wa, wp, 0);
+  ba = xl[0];
+  int it = 0;
+#pragma unroll 1
+  for (; it + 1 < n_it; it += 2) {
+    load_w<NBO>(wb, wp, it + 1);
+    bb = xl[(it + 1) * 64];
+    mma4<NBO>(acc, wa, ba);
+    if (it + 2 < n_it) {
+      load_w<NBO>(wa, wp, it + 2);
+      ba = xl[(it + 2) * 64];
+    }
+    mma4<NBO>(acc, wb, bb);
+  }
+  if (it < n_it) mma4<NBO>(acc, wa, ba);
+}
+
+template <int NBO>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+}
+
+// X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3] + bias[nb*32 + 8q + 4h ..])
+template <int NBO, int NBS, bool RELU>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], const float* __restrict__ bias, float4* xl, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NBS; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
+      float4 v;
+      v.x = acc[nb][4 * q + 0] + bv.x;
+      v.y = acc[nb][4 * q + 1] + bv.y;
+      v.z = acc[nb][4 * q + 2] + bv.z;
+      v.w = acc[nb][4 * q + 3] + bv.w;
+      if (RELU) {
+        v.x = fmaxf(v.x, 0.0f);
+        v.y = fmaxf(v.y, 0.0f);
+        v.z = fmaxf(v.z, 0.0f);
+        v.w = fmaxf(v.w, 0.0f);
+      }
+      xl[(nb * 4 + q) * 64] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
+  constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;  // >= 13 (encoding) and >= 16 (mid hidden)
+  constexpr int WAVE_F4 = (XITS + RSN_SH_ITS) * 64;
+  constexpr int W = NB * 32;
+  __shared__ float4 smem[4 * WAVE_F4];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  float4* X = smem + wid * WAVE_F4 + lane;
+  float4* AUX = X + XITS * 64;
+  float* Xf = reinterpret_cast<float*>(X);
+
+  int n_rays = a.n_rays;
+  if (a.n_dev) {
+    const int nd = *a.n_dev;
+    n_rays = nd < n_rays ? nd : n_rays;
+  }
+  const long long n_points = (long long)n_rays * a.S;
+  const long long n_tiles = (n_points + 127) / 128;
+  const float* __restrict__ pk = a.packed;
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long p0 = tile * 128 + wid * 32;
+    if (p0 >= n_points) continue;  // wave-uniform; waves never synchronise with each other
+    const long long p = p0 + m;
+    const bool valid = p < n_points;
+    const long long pc = valid ? p : n_points - 1;
+
+    // ---------------- encode -----------------
+    float mc[3], vc[3], vd[3];
+    bool has_cov = true, has_dir = true;
+    if (a.mode == RSN_MODE_FRUSTUM) {
+      const long long ray = pc / a.S;
+      const int s = (int)(pc - ray * a.S);
+      float o[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o[c] = a.origins[ray * 3 + c];
+        vd[c] = a.directions[ray * 3 + c];
+      }
+      const float pa = a.pixel_area[ray];
+      const float t0 = a.bins[ray * (a.S + 1) + s];
+      const float t1 = a.bins[ray * (a.S + 1) + s + 1];
+      frustum_to_contracted(o, vd, pa, t0, t1, mc, vc);
+    } else if (a.mode == RSN_MODE_INF) {
+      const float r2 = a.sqradius[pc];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        vd[c] = a.directions[pc * 3 + c];
+        mc[c] = 2.0f * vd[c];
+        vc[c] = (0.6f * r2) * (1.0f - vd[c] * vd[c]);
+      }
+      has_dir = false;  // SH inputs are zeroed (reflect_sampling_nerf_field.py:199)
+    } else {
+      has_cov = a.cov_diag != nullptr;
+      has_dir = a.view_dirs != nullptr;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        mc[c] = a.means[pc * 3 + c];
+        vc[c] = has_cov ? a.cov_diag[pc * 3 + c] : 0.0f;
+        vd[c] = has_dir ? a.view_dirs[pc * 3 + c] : 0.0f;
+      }
+    }
+
+    // integrated positional encoding (nerfstudio NeRFEncoding, N2): this lane produces the features of
+    // frequencies 8h..8h+7 into its own LDS slots (slot order: rsn_pack.hip cols_encoding).
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      const float x = (c == 0) ? mc[0] : (c == 1 ? mc[1] : mc[2]);
+      const float v = (c == 0) ? vc[0] : (c == 1 ? vc[1] : vc[2]);
+      const float sx = 6.283185307179586f * x;
+#pragma unroll 2
+      for (int jj = 0; jj < 8; ++jj) {
+        const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
+        const float ang = sx * f;
+        const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
+        const float fs = e * sinf(ang);
+        const float fc = e * sinf(ang + 1.5707963267948966f);
+        const int u = c * 8 + jj;
+        Xf[(u >> 2) * 256 + (u & 3)] = fs;
+        Xf[((u + 24) >> 2) * 256 + ((u + 24) & 3)] = fc;
+      }
+    }
+    {
+      float4 raw = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (h == 0) raw = make_float4(mc[0], mc[1], mc[2], 0.0f);
+      X[12 * 64] = raw;
+    }
+    float4 stash[RSN_ENC_ITS];  // this lane's encoded inputs, re-used by the skip layer
+#pragma unroll
+    for (int it = 0; it < RSN_ENC_ITS; ++it) stash[it] = X[it * 64];
+
+    // ---------------- trunk -----------------
+    {
+      f32x16 acc[NB];
+      zero_acc<NB>(acc);
+      gemm<NB>(acc, pk + a.L.w_enc0, X, RSN_ENC_ITS, lane);
+      store_act<NB, NB, true>(acc, pk + a.L.b[0], X, h);
+#pragma unroll 1
+      for (int l = 1; l < a.num_layers; ++l) {
+        zero_acc<NB>(acc);
+        gemm<NB>(acc, pk + a.L.w_x[l], X, NB * 4, lane);
+        if (l == a.skip_layer) {
+#pragma unroll
+          for (int it = 0; it < RSN_ENC_ITS; ++it) X[it * 64] = stash[it];
+          gemm<NB>(acc, pk + a.L.w_enc_skip, X, RSN_ENC_ITS, lane);
+        }
+        store_act<NB, NB, true>(acc, pk + a.L.b[l], X, h);  // ReLU between layers and out_activation=ReLU
+      }
+    }
+    if (a.embedding && valid) {
+#pragma unroll 4
+      for (int it = 0; it < NB * 4; ++it)
+        *reinterpret_cast<float4*>(a.embedding + pc * W + it * 8 + 4 * h) = X[it * 64];
+    }
+
+    // ---------------- bottleneck + heads (one GEMM, N = W + 32) -----------------
+    float dcol[3], tcol[3], rho;
+    {
+      f32x16 acc[NB + 1];
+      zero_acc<NB + 1>(acc);
+      gemm<NB + 1>(acc, pk + a.L.w_bh, X, NB * 4, lane);
+      const float* __restrict__ bh = pk + a.L.b_bh + W;
+      const float r0 = acc[NB][0] + bh[4 * h + 0];
+      const float r1 = acc[NB][1] + bh[4 * h + 1];
+      const float r2 = acc[NB][2] + bh[4 * h + 2];
+      const float r3 = acc[NB][3] + bh[4 * h + 3];
+      const float r4 = acc[NB][4] + bh[8 + 4 * h + 0];
+      const float r5 = acc[NB][5] + bh[8 + 4 * h + 1];
+      const float r6 = acc[NB][6] + bh[8 + 4 * h + 2];
+      // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
+      const float rough_raw = __shfl(r4, m, 64);
+      rho = softplus_f(rough_raw);
+      dcol[0] = sigmoid_f(r0); dcol[1] = sigmoid_f(r1); dcol[2] = sigmoid_f(r2);
+      tcol[0] = sigmoid_f(r4); tcol[1] = sigmoid_f(r5); tcol[2] = sigmoid_f(r6);
+      if (a.mode != RSN_MODE_INF && valid) {
+        if (h == 0) {
+          // get_pred_normals: -normalize(head) then normalize again (field.py:139-144, N6)
+          float nrm = fmaxf(sqrtf(r1 * r1 + r2 * r2 + r3 * r3), 1e-12f);
+          float nx = -(r1 / nrm), ny = -(r2 / nrm), nz = -(r3 / nrm);
+          nrm = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
+          nx /= nrm; ny /= nrm; nz /= nrm;
+          if (a.out.sigma) a.out.sigma[pc] = softplus_f(r0 + a.density_bias);
+          if (a.out.raw_density) a.out.raw_density[pc] = r0;
+          if (a.out.pred_normals) {
+            a.out.pred_normals[pc * 3 + 0] = nx;
+            a.out.pred_normals[pc * 3 + 1] = ny;
+            a.out.pred_normals[pc * 3 + 2] = nz;
+          }
+          if (a.out.n_dot_d) a.out.n_dot_d[pc] = vd[0] * nx + vd[1] * ny + vd[2] * nz;
+          if (a.out.roughness) a.out.roughness[pc] = sigmoid_f(r4);
+        } else {
+          if (a.out.diff) {
+            a.out.diff[pc * 3 + 0] = dcol[0]; a.out.diff[pc * 3 + 1] = dcol[1]; a.out.diff[pc * 3 + 2] = dcol[2];
+          }
+          if (a.out.tint) {
+            a.out.tint[pc * 3 + 0] = tcol[0]; a.out.tint[pc * 3 + 1] = tcol[1]; a.out.tint[pc * 3 + 2] = tcol[2];
+          }
+        }
+      }
+      // bottleneck output (no activation) becomes the x-part of mlp_mid's input
+      store_act<NB + 1, NB, false>(acc, pk + a.L.b_bh, X, h);
+    }
+
+    // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
+    {
+      float sh[34];
+      if (has_dir) {
+        sh34_attenuated(vd[0], vd[1], vd[2], rho, sh);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 34; ++i) sh[i] = 0.0f;
+      }
+#pragma unroll
+      for (int it = 0; it < RSN_SH_ITS; ++it) {
+        float vals[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int u = it * 4 + s;
+          vals[s] = (u < 17) ? (h ? sh[17 + u] : sh[u]) : 0.0f;
+        }
+        AUX[it * 64] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+      }
+    }
+
+    // ---------------- mlp_mid + RGB head -----------------
+    {
+      f32x16 accm[4];
+      zero_acc<4>(accm);
+      gemm<4>(accm, pk + a.L.w_mid_sh, AUX, RSN_SH_ITS, lane);
+      gemm<4>(accm, pk + a.L.w_mid_x, X, NB * 4, lane);
+      store_act<4, 4, true>(accm, pk + a.L.b_mid, X, h);
+    }
+    {
+      f32x16 accr[1];
+      zero_acc<1>(accr);
+      gemm<1>(accr, pk + a.L.w_rgb, X, 16, lane);
+      if (h == 1 && valid) {
+        const float* __restrict__ br = pk + a.L.b_rgb;
+        const float m0 = sigmoid_f(accr[0][0] + br[4]);
+        const float m1 = sigmoid_f(accr[0][1] + br[5]);
+        const float m2 = sigmoid_f(accr[0][2] + br[6]);
+        if (a.out.color) {
+          if (a.mode == RSN_MODE_INF) {
+            a.out.color[pc * 3 + 0] = m0; a.out.color[pc * 3 + 1] = m1; a.out.color[pc * 3 + 2] = m2;
+          } else {
+            a.out.color[pc * 3 + 0] = dcol[0] + tcol[0] * m0;
+            a.out.color[pc * 3 + 1] = dcol[1] + tcol[1] * m1;
+            a.out.color[pc * 3 + 2] = dcol[2] + tcol[2] * m2;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
+  int rc = rsn_compute_layout(d, &a.L);
+  if (rc != RSN_OK) return rc;
+  RSN_REQUIRE(a.packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "packed weights pointer is NULL");
+  a.num_layers = d->num_layers;
+  a.skip_layer = d->skip_layer;
+  a.width = d->width;
+  a.density_bias = d->density_bias;
+  for (int i = 0; i < RSN_NUM_FREQS; ++i) a.freqs[i] = d->freqs[i];
+  if (a.n_rays <= 0) return RSN_OK;
+  const long long n_points = (long long)a.n_rays * a.S;
+  const long long n_tiles = (n_points + 127) / 128;
+  static int cached_cus = 0;  // CU count of the current device (256 on MI355X), queried once
+  if (cached_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cached_cus = n;
+    else
+      cached_cus = 256;
+  }
+  const int cus = cached_cus;
+  // one 4-wave workgroup per CU (one wave per SIMD, LDS slab 148 KiB at W=256): persistent tiles
+  const long long grid = n_tiles < (long long)cus ? n_tiles : (long long)cus;
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->width) {
+    case 256: hipLaunchKernelGGL(rsn_field_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    case 128: hipLaunchKernelGGL(rsn_field_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL(rsn_field_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    default: RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "width=%d unsupported", d->width);
+  }
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+extern "C" int rsn_field_forward_frustum(const rsn_field_desc* desc, const float* packed, int32_t n_rays,
+                                         const int32_t* n_dev, int32_t n_samples, const float* origins,
+                                         const float* directions, const float* pixel_area, const float* euclid_bins,
+                                         const rsn_field_outputs* out, void* stream) {
+  RSN_REQUIRE(desc && out, RSN_ERR_INVALID_ARGUMENT, "desc/out is NULL");
+  RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
+  RSN_REQUIRE(n_rays == 0 || (origins && directions && pixel_area && euclid_bins), RSN_ERR_INVALID_ARGUMENT,
+              "a ray input pointer is NULL");
+  FieldArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_FRUSTUM;
+  a.n_rays = n_rays; a.n_dev = n_dev; a.S = n_samples;
+  a.origins = origins; a.directions = directions; a.pixel_area = pixel_area; a.bins = euclid_bins;
+  a.out = *out;
+  return launch_field(desc, a, stream);
+}
+
+extern "C" int rsn_field_forward_inf(const rsn_field_desc* desc, const float* packed, int32_t n_rays,
+                                     const int32_t* n_dev, const float* directions, const float* sqradius,
+                                     float* out_rgb, void* stream) {
+  RSN_REQUIRE(desc, RSN_ERR_INVALID_ARGUMENT, "desc is NULL");
+  RSN_REQUIRE(n_rays >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
+  RSN_REQUIRE(n_rays == 0 || (directions && sqradius && out_rgb), RSN_ERR_INVALID_ARGUMENT, "an input pointer is NULL");
+  FieldArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_INF;
+  a.n_rays = n_rays; a.n_dev = n_dev; a.S = 1;
+  a.directions = directions; a.sqradius = sqradius;
+  a.out.color = out_rgb;
+  return launch_field(desc, a, stream);
+}
+
+extern "C" int rsn_field_forward_gaussians(const rsn_field_desc* desc, const float* packed, int32_t n_points,
+                                           const float* means, const float* cov_diag, const float* view_dirs,
+                                           const rsn_field_outputs* out, float* embedding, void* stream) {
+  RSN_REQUIRE(desc && out, RSN_ERR_INVALID_ARGUMENT, "desc/out is NULL");
+  RSN_REQUIRE(n_points >= 0, RSN_ERR_INVALID_ARGUMENT, "n_points=%d", n_points);
+  RSN_REQUIRE(n_points == 0 || means, RSN_ERR_INVALID_ARGUMENT, "means is NULL");
+  FieldArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_GAUSS;
+  a.n_rays = n_points; a.n_dev = nullptr; a.S = 1;
+  a.means = means; a.cov_diag = cov_diag; a.view_dirs = view_dirs;
+  a.out = *out;
+  a.embedding = embedding;
+  return launch_field(desc, a, stream);
+}

@@ -1,0 +1,279 @@
+// Weight packing: torch.nn.Linear layout -> the fragment order of v_mfma_f32_32x32x2_f32.
+//
+// Data layout in HBM (see DESIGN.md "Packed weights"): one flat fp32 buffer; every segment is
+// [it][nb][lane][4] so that a wave streams it with 1 KiB-contiguous global_load_dwordx4's.
+// The K index is a free permutation (it only changes the summation order); it is chosen so that the
+// accumulator registers a lane holds after one layer are exactly the B-operand values the same
+// lane needs for the next layer (no cross-lane movement between layers, rsn_field.hip).
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+
+#include "rsn_common.h"
+
+static thread_local std::string g_last_error;
+
+void rsn_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+extern "C" const char* rsn_last_error(void) { return g_last_error.c_str(); }
+extern "C" int rsn_abi_version(void) { return RSN_ABI_VERSION; }
+
+int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
+  RSN_REQUIRE(d != nullptr, RSN_ERR_INVALID_ARGUMENT, "desc is NULL");
+  RSN_REQUIRE(d->num_layers >= 1 && d->num_layers <= RSN_MAX_TRUNK_LAYERS, RSN_ERR_INVALID_ARGUMENT,
+              "num_layers=%d out of range [1,%d]", d->num_layers, RSN_MAX_TRUNK_LAYERS);
+  RSN_REQUIRE(d->width == 64 || d->width == 128 || d->width == 256, RSN_ERR_UNSUPPORTED,
+              "width=%d unsupported (64, 128 or 256)", d->width);
+  RSN_REQUIRE(d->mid_width == 128, RSN_ERR_UNSUPPORTED, "mid_width=%d unsupported (128)", d->mid_width);
+  RSN_REQUIRE(d->skip_layer == -1 || (d->skip_layer >= 1 && d->skip_layer <= d->num_layers - 2),
+              RSN_ERR_INVALID_ARGUMENT,
+              "skip_layer=%d invalid for num_layers=%d (the reference MLP raises a shape error when the skip "
+              "index is the last layer)", d->skip_layer, d->num_layers);
+  memset(L, 0, sizeof(*L));
+  L->nb = d->width / 32;
+  L->nbm = d->mid_width / 32;
+  const size_t blk = 256;  // floats per (it, nb) chunk: 64 lanes x 4
+  size_t off = 0;
+  const size_t x_seg = (size_t)(L->nb * 4) * L->nb * blk;
+  const size_t enc_seg = (size_t)RSN_ENC_ITS * L->nb * blk;
+  for (int l = 0; l < d->num_layers; ++l) {
+    if (l == 0) {
+      L->w_enc0 = off;
+      off += enc_seg;
+    } else {
+      L->w_x[l] = off;
+      off += x_seg;
+      if (l == d->skip_layer) {
+        L->w_enc_skip = off;
+        off += enc_seg;
+      }
+    }
+    L->b[l] = off;
+    off += (size_t)d->width;
+  }
+  L->w_bh = off;
+  off += (size_t)(L->nb * 4) * (L->nb + 1) * blk;
+  L->b_bh = off;
+  off += (size_t)(L->nb + 1) * 32;
+  L->w_mid_sh = off;
+  off += (size_t)RSN_SH_ITS * L->nbm * blk;
+  L->w_mid_x = off;
+  off += (size_t)(L->nb * 4) * L->nbm * blk;
+  L->b_mid = off;
+  off += (size_t)d->mid_width;
+  L->w_rgb = off;
+  off += (size_t)(L->nbm * 4) * 1 * blk;
+  L->b_rgb = off;
+  off += 32;
+  L->total = off;
+  return RSN_OK;
+}
+
+extern "C" size_t rsn_packed_weights_bytes(const rsn_field_desc* desc) {
+  RsnPackedLayout L;
+  if (rsn_compute_layout(desc, &L) != RSN_OK) return 0;
+  return L.total * sizeof(float);
+}
+
+// ---- one pack job = one segment -------------------------------------------------------------------
+#define PACK_MAX_ROWS 288
+#define PACK_MAX_COLS 256
+#define PACK_MAX_SRC 6
+
+struct PackJob {
+  const float* src[PACK_MAX_SRC];
+  int ld[PACK_MAX_SRC];
+  float* dst;
+  int n_it, nbo, is_bias, n_rows;
+  int16_t row_src[PACK_MAX_ROWS];  // which src a packed row comes from, -1 = zero row
+  int16_t row_idx[PACK_MAX_ROWS];  // row inside that src
+  int16_t col[PACK_MAX_COLS];      // source column of packed k, -1 = zero
+};
+
+__global__ void rsn_pack_kernel(const PackJob job) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (job.is_bias) {
+    if (e < job.n_rows) {
+      const int rs = job.row_src[e];
+      job.dst[e] = rs >= 0 ? job.src[rs][job.row_idx[e]] : 0.0f;
+    }
+    return;
+  }
+  const int total = job.n_it * job.nbo * 256;
+  if (e >= total) return;
+  const int s = e & 3;
+  const int lane = (e >> 2) & 63;
+  const int chunk = e >> 8;
+  const int nb = chunk % job.nbo;
+  const int it = chunk / job.nbo;
+  const int n = nb * 32 + (lane & 31);
+  const int k = it * 8 + 4 * (lane >> 5) + s;
+  const int rs = job.row_src[n];
+  const int c = job.col[k];
+  float v = 0.0f;
+  if (rs >= 0 && c >= 0) v = job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
+  job.dst[e] = v;
+}
+
+namespace {
+
+void rows_natural(PackJob& j, int n_rows, int src = 0) {
+  for (int n = 0; n < n_rows; ++n) {
+    j.row_src[n] = (int16_t)src;
+    j.row_idx[n] = (int16_t)n;
+  }
+}
+
+void cols_natural(PackJob& j, int n_cols, int offset) {
+  for (int k = 0; k < n_cols; ++k) j.col[k] = (int16_t)(offset + k);
+}
+
+// Encoded-input order: lane half h owns frequencies 8h..8h+7.  Slot u of a lane:
+//   u in [0,24):  exp*sin  of (coord c = u/8, freq 8h + u%8)   -> reference column c*16 + f
+//   u in [24,48): exp*sin(.+pi/2) of the same                 -> reference column 48 + c*16 + f
+//   u in [48,51): raw coordinate c (h == 0 only)              -> reference column 96 + c
+// packed k = (u/4)*8 + 4h + u%4.            (NeRFEncoding column order: SURVEY §8(a) N2)
+void cols_encoding(PackJob& j) {
+  for (int k = 0; k < RSN_K_ENC_PAD; ++k) {
+    const int it = k >> 3, h = (k >> 2) & 1, s = k & 3;
+    const int u = it * 4 + s;
+    int c = -1;
+    if (u < 24) {
+      c = (u / 8) * 16 + 8 * h + (u % 8);
+    } else if (u < 48) {
+      c = 48 + ((u - 24) / 8) * 16 + 8 * h + ((u - 24) % 8);
+    } else if (u < 51 && h == 0) {
+      c = 96 + (u - 48);
+    }
+    j.col[k] = (int16_t)c;
+  }
+}
+
+// SH order: lane half h owns components 17h .. 17h+16 in slots 0..16 (slots 17..19 zero).
+void cols_sh(PackJob& j) {
+  for (int k = 0; k < RSN_K_SH_PAD; ++k) {
+    const int it = k >> 3, h = (k >> 2) & 1, s = k & 3;
+    const int u = it * 4 + s;
+    j.col[k] = (int16_t)(u < 17 ? 17 * h + u : -1);
+  }
+}
+
+int launch(const PackJob& j, hipStream_t st) {
+  const int total = j.is_bias ? j.n_rows : j.n_it * j.nbo * 256;
+  const int threads = 256;
+  hipLaunchKernelGGL(rsn_pack_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, j);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+void clear_job(PackJob& j) {
+  memset(&j, 0, sizeof(j));
+  for (int i = 0; i < PACK_MAX_ROWS; ++i) j.row_src[i] = -1;
+  for (int i = 0; i < PACK_MAX_COLS; ++i) j.col[i] = -1;
+}
+
+}  // namespace
+
+extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params* p, float* packed,
+                                size_t packed_bytes, void* stream) {
+  RsnPackedLayout L;
+  int rc = rsn_compute_layout(d, &L);
+  if (rc != RSN_OK) return rc;
+  RSN_REQUIRE(p != nullptr && packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "params/packed is NULL");
+  RSN_REQUIRE(packed_bytes >= L.total * sizeof(float), RSN_ERR_WORKSPACE,
+              "packed buffer too small: %zu < %zu bytes", packed_bytes, L.total * sizeof(float));
+  hipStream_t st = (hipStream_t)stream;
+  const int W = d->width, NB = L.nb, NBM = L.nbm;
+  PackJob j;
+
+  for (int l = 0; l < d->num_layers; ++l) {
+    RSN_REQUIRE(p->trunk_w[l] && p->trunk_b[l], RSN_ERR_INVALID_ARGUMENT, "trunk layer %d has NULL parameters", l);
+    const int in_f = (l == 0) ? RSN_ENC_DIM : (l == d->skip_layer ? RSN_ENC_DIM + W : W);
+    if (l == 0) {
+      clear_job(j);
+      j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; j.dst = packed + L.w_enc0; j.n_it = RSN_ENC_ITS; j.nbo = NB;
+      rows_natural(j, W); cols_encoding(j);
+      if ((rc = launch(j, st)) != RSN_OK) return rc;
+    } else {
+      clear_job(j);
+      j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; j.dst = packed + L.w_x[l]; j.n_it = NB * 4; j.nbo = NB;
+      rows_natural(j, W);
+      cols_natural(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0);  // cat([encoding, x]): x columns come second
+      if ((rc = launch(j, st)) != RSN_OK) return rc;
+      if (l == d->skip_layer) {
+        clear_job(j);
+        j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; j.dst = packed + L.w_enc_skip; j.n_it = RSN_ENC_ITS; j.nbo = NB;
+        rows_natural(j, W); cols_encoding(j);
+        if ((rc = launch(j, st)) != RSN_OK) return rc;
+      }
+    }
+    clear_job(j);
+    j.is_bias = 1; j.src[0] = p->trunk_b[l]; j.dst = packed + L.b[l]; j.n_rows = W;
+    rows_natural(j, W);
+    if ((rc = launch(j, st)) != RSN_OK) return rc;
+  }
+
+  RSN_REQUIRE(p->density_w && p->normals_w && p->roughness_w && p->diff_w && p->tint_w && p->bottleneck_w &&
+                  p->mid_w && p->rgb_w && p->density_b && p->normals_b && p->roughness_b && p->diff_b &&
+                  p->tint_b && p->bottleneck_b && p->mid_b && p->rgb_b,
+              RSN_ERR_INVALID_ARGUMENT, "a head parameter pointer is NULL");
+
+  // bottleneck (blocks 0..NB-1) + heads block NB.  Heads rows (so that MFMA C rows land where the
+  // epilogue wants them): 0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint.
+  auto heads_rows = [&](PackJob& jj, int base) {
+    jj.row_src[base + 0] = 1; jj.row_idx[base + 0] = 0;
+    for (int c = 0; c < 3; ++c) {
+      jj.row_src[base + 1 + c] = 2;  jj.row_idx[base + 1 + c] = (int16_t)c;
+      jj.row_src[base + 4 + c] = 3;  jj.row_idx[base + 4 + c] = (int16_t)c;
+      jj.row_src[base + 12 + c] = 5; jj.row_idx[base + 12 + c] = (int16_t)c;
+    }
+    jj.row_src[base + 8] = 4; jj.row_idx[base + 8] = 0;
+  };
+  clear_job(j);
+  j.src[0] = p->bottleneck_w; j.src[1] = p->density_w; j.src[2] = p->normals_w; j.src[3] = p->diff_w;
+  j.src[4] = p->roughness_w; j.src[5] = p->tint_w;
+  for (int i = 0; i < PACK_MAX_SRC; ++i) j.ld[i] = W;
+  j.dst = packed + L.w_bh; j.n_it = NB * 4; j.nbo = NB + 1;
+  rows_natural(j, W); heads_rows(j, W); cols_natural(j, W, 0);
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+  clear_job(j);
+  j.is_bias = 1; j.n_rows = W + 32; j.dst = packed + L.b_bh;
+  j.src[0] = p->bottleneck_b; j.src[1] = p->density_b; j.src[2] = p->normals_b; j.src[3] = p->diff_b;
+  j.src[4] = p->roughness_b; j.src[5] = p->tint_b;
+  rows_natural(j, W); heads_rows(j, W);
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+
+  // mlp_mid: input cat([SH(34), bottleneck(W)])
+  clear_job(j);
+  j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; j.dst = packed + L.w_mid_sh; j.n_it = RSN_SH_ITS; j.nbo = NBM;
+  rows_natural(j, d->mid_width); cols_sh(j);
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+  clear_job(j);
+  j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; j.dst = packed + L.w_mid_x; j.n_it = NB * 4; j.nbo = NBM;
+  rows_natural(j, d->mid_width); cols_natural(j, W, RSN_SH_DIM);
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+  clear_job(j);
+  j.is_bias = 1; j.n_rows = d->mid_width; j.src[0] = p->mid_b; j.dst = packed + L.b_mid;
+  rows_natural(j, d->mid_width);
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+
+  // field_output_mid (RGB head): rows 4..6 of one 32-row block
+  clear_job(j);
+  j.src[0] = p->rgb_w; j.ld[0] = d->mid_width; j.dst = packed + L.w_rgb; j.n_it = NBM * 4; j.nbo = 1;
+  for (int c = 0; c < 3; ++c) { j.row_src[4 + c] = 0; j.row_idx[4 + c] = (int16_t)c; }
+  cols_natural(j, d->mid_width, 0);
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+  clear_job(j);
+  j.is_bias = 1; j.n_rows = 32; j.src[0] = p->rgb_b; j.dst = packed + L.b_rgb;
+  for (int c = 0; c < 3; ++c) { j.row_src[4 + c] = 0; j.row_idx[4 + c] = (int16_t)c; }
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+  return RSN_OK;
+}

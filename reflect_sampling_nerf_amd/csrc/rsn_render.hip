@@ -1,0 +1,422 @@
+// rsn_render.hip -- the HBM-side kernels around the field: samplers, compositing, reflection rays.
+// All are per-ray, coalesced and tiny next to rsn_field.hip (a few bytes per sample); one wavefront
+// (64 lanes) owns one ray wherever a scan along the ray is needed.
+//
+// Reference semantics restated: nerfstudio SpacedSampler/PDFSampler/get_weights/renderers (SURVEY
+// §8(a) N5, N7-N11), reflect_sampling_nerf_components.py:14-36 (reciprocal spacing),
+// reflect_sampling_nerf_model.py:215-229,240-241,267-289,312-313,338-339.
+#include "rsn_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dyn_count(int n_host, const int* n_dev) {
+  if (!n_dev) return n_host;
+  const int nd = *n_dev;
+  return nd < n_host ? nd : n_host;
+}
+
+// torch.linspace(start=0, end, steps) element idx (fp32, symmetric evaluation like ATen's CPU kernel)
+__device__ __forceinline__ float linspace0(float end, int steps, int idx) {
+  if (steps <= 1) return 0.0f;
+  const float step = end / (float)(steps - 1);
+  return idx < steps / 2 ? step * (float)idx : end - step * (float)(steps - idx - 1);
+}
+
+__device__ __forceinline__ float spacing_fn(int kind, float tan_, float x) {
+  return kind == RSN_SPACING_RECIPROCAL ? x / (1.0f / tan_ + x) : x;
+}
+__device__ __forceinline__ float spacing_inv(int kind, float tan_, float x) {
+  return kind == RSN_SPACING_RECIPROCAL ? x / tan_ / (1.0f - x) : x;
+}
+__device__ __forceinline__ float to_euclid(int kind, float tan_, float b, float s_near, float s_far) {
+  return spacing_inv(kind, tan_, b * s_far + (1.0f - b) * s_near);
+}
+
+__device__ __forceinline__ float nan_to_num_f(float x) {
+  if (x != x) return 0.0f;
+  if (x == __builtin_huge_valf()) return 3.4028234663852886e38f;
+  if (x == -__builtin_huge_valf()) return -3.4028234663852886e38f;
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// spaced sampler (uniform / reciprocal), N7/N8/F12
+// ---------------------------------------------------------------------------------------------------
+__global__ void rsn_sample_spaced_kernel(int n_rays, const int* n_dev, int S, int kind, float tan_, const float* nears,
+                                         const float* fars, const float* t_rand, float* spacing_bins,
+                                         float* euclid_bins) {
+  const int R = dyn_count(n_rays, n_dev);
+  const long long total = (long long)R * (S + 1);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int ray = (int)(e / (S + 1));
+    const int k = (int)(e - (long long)ray * (S + 1));
+    float b = linspace0(1.0f, S + 1, k);
+    if (t_rand) {
+      const float bl = linspace0(1.0f, S + 1, k > 0 ? k - 1 : 0);
+      const float bu = linspace0(1.0f, S + 1, k < S ? k + 1 : S);
+      const float lower = (k == 0) ? b : (b + bl) / 2.0f;
+      const float upper = (k == S) ? b : (bu + b) / 2.0f;
+      b = lower + (upper - lower) * t_rand[e];
+    }
+    const float s_near = spacing_fn(kind, tan_, nears[ray]);
+    const float s_far = spacing_fn(kind, tan_, fars[ray]);
+    spacing_bins[e] = b;
+    euclid_bins[e] = to_euclid(kind, tan_, b, s_near, s_far);
+  }
+}
+
+extern "C" int rsn_sample_spaced(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t spacing, float tan_,
+                                 const float* nears, const float* fars, const float* t_rand, float* spacing_bins,
+                                 float* euclid_bins, void* stream) {
+  RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
+  RSN_REQUIRE(spacing == RSN_SPACING_UNIFORM || spacing == RSN_SPACING_RECIPROCAL, RSN_ERR_INVALID_ARGUMENT,
+              "spacing=%d", spacing);
+  if (n_rays == 0) return RSN_OK;
+  RSN_REQUIRE(nears && fars && spacing_bins && euclid_bins, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  const long long total = (long long)n_rays * (n_samples + 1);
+  const int threads = 256;
+  long long blocks = (total + threads - 1) / threads;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rsn_sample_spaced_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, n_rays,
+                     n_dev, n_samples, spacing, tan_, nears, fars, t_rand, spacing_bins, euclid_bins);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PDF sampler (inverse CDF), N9.  One wave per ray; CDF and the existing bins live in LDS.
+// ---------------------------------------------------------------------------------------------------
+#define PDF_MAX_S 1024
+
+__global__ __launch_bounds__(256) void rsn_sample_pdf_kernel(int n_rays, const int* n_dev, int s_in, int s_out, int kind,
+                                                             float tan_, float hist_pad, const float* nears,
+                                                             const float* fars, const float* weights,
+                                                             const float* bins_in, const float* u_rand,
+                                                             float* bins_out, float* euclid_out) {
+  __shared__ float s_cdf[4][PDF_MAX_S + 1];
+  __shared__ float s_bins[4][PDF_MAX_S + 1];
+  const int R = dyn_count(n_rays, n_dev);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* cdf = s_cdf[wid];
+  float* eb = s_bins[wid];
+  for (int ray = blockIdx.x * 4 + wid; ray < R; ray += gridDim.x * 4) {
+    const float* w = weights + (long long)ray * s_in;
+    // weights + histogram padding, their sum
+    float part = 0.0f;
+    for (int i = lane; i < s_in; i += 64) part += w[i] + hist_pad;
+    float wsum = wave_sum(part);
+    const float eps = 1e-5f;
+    const float padding = fmaxf(eps - wsum, 0.0f);
+    const float padd = padding / (float)s_in;
+    wsum += padding;
+    // cdf = min(1, cumsum(pdf)), with a leading 0
+    float carry = 0.0f;
+    for (int base = 0; base < s_in; base += 64) {
+      const int i = base + lane;
+      const float pdf = (i < s_in) ? ((w[i] + hist_pad) + padd) / wsum : 0.0f;
+      const float inc = wave_scan_incl(pdf, lane) + carry;
+      if (i < s_in) cdf[i + 1] = fminf(1.0f, inc);
+      carry = __shfl(inc, 63, 64);
+    }
+    if (lane == 0) cdf[0] = 0.0f;
+    for (int i = lane; i <= s_in; i += 64) eb[i] = bins_in[(long long)ray * (s_in + 1) + i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are visible to its own reads
+    const int nb = s_out + 1;
+    const float u_end = (float)(1.0 - (1.0 / (double)nb));
+    const float s_near = spacing_fn(kind, tan_, nears[ray]);
+    const float s_far = spacing_fn(kind, tan_, fars[ray]);
+    for (int j = lane; j < nb; j += 64) {
+      float u = linspace0(u_end, nb, j);
+      if (u_rand) {
+        u = u + u_rand[(long long)ray * nb + j] / (float)nb;
+      } else {
+        u = u + (float)(1.0 / (2.0 * (double)nb));
+      }
+      // searchsorted(cdf, u, side="right"): first index with cdf[idx] > u
+      int lo = 0, hi = s_in + 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+      }
+      int below = lo - 1;
+      below = below < 0 ? 0 : (below > s_in ? s_in : below);
+      const int above = lo > s_in ? s_in : lo;
+      const float c0 = cdf[below], c1 = cdf[above];
+      const float b0 = eb[below], b1 = eb[above];
+      float t = (u - c0) / (c1 - c0);
+      if (t != t) t = 0.0f;                       // nan_to_num(., 0)
+      t = nan_to_num_f(t);
+      t = fminf(fmaxf(t, 0.0f), 1.0f);
+      const float b = b0 + t * (b1 - b0);
+      const long long o = (long long)ray * nb + j;
+      bins_out[o] = b;
+      euclid_out[o] = to_euclid(kind, tan_, b, s_near, s_far);
+    }
+  }
+}
+
+extern "C" int rsn_sample_pdf(int32_t n_rays, const int32_t* n_dev, int32_t s_in, int32_t s_out, int32_t spacing,
+                              float tan_, float histogram_padding, const float* nears, const float* fars,
+                              const float* weights, const float* spacing_bins_in, const float* u_rand,
+                              float* spacing_bins_out, float* euclid_bins_out, void* stream) {
+  RSN_REQUIRE(n_rays >= 0 && s_in >= 1 && s_out >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d s_in=%d s_out=%d", n_rays,
+              s_in, s_out);
+  RSN_REQUIRE(s_in <= PDF_MAX_S, RSN_ERR_UNSUPPORTED, "s_in=%d > %d", s_in, PDF_MAX_S);
+  if (n_rays == 0) return RSN_OK;
+  RSN_REQUIRE(nears && fars && weights && spacing_bins_in && spacing_bins_out && euclid_bins_out,
+              RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  int blocks = (n_rays + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rsn_sample_pdf_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_rays, n_dev, s_in, s_out,
+                     spacing, tan_, histogram_padding, nears, fars, weights, spacing_bins_in, u_rand, spacing_bins_out,
+                     euclid_bins_out);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// compositing: weights (N5) + RGB / accumulation / median depth / normals / semantic renderers (N10, N11).
+// One wave per ray; exclusive prefix sum of delta*sigma by a wave-level scan with a running carry.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rsn_composite_kernel(int n_rays, const int* n_dev, int S, int background,
+                                                            int flags, const rsn_composite_io io) {
+  const int eval_mode = flags & RSN_COMP_EVAL;
+  const int clip_rgb = flags & (RSN_COMP_EVAL | RSN_COMP_CLIP_RGB);
+  const int R = dyn_count(n_rays, n_dev);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int ray = blockIdx.x * 4 + wid; ray < R; ray += gridDim.x * 4) {
+    const long long sbase = (long long)ray * S;
+    const float* bins = io.euclid_bins + (long long)ray * (S + 1);
+    float carry_dd = 0.0f, carry_w = 0.0f;
+    float acc = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, t0s = 0.0f, t1s = 0.0f, t2s = 0.0f;
+    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, rs = 0.0f;
+    int median_idx = -1;
+    for (int base = 0; base < S; base += 64) {
+      const int i = base + lane;
+      const bool in = i < S;
+      float ta = 0.0f, tb = 0.0f, sg = 0.0f;
+      if (in) {
+        ta = bins[i];
+        tb = bins[i + 1];
+        sg = io.sigma[sbase + i];
+      }
+      const float dd = in ? (tb - ta) * sg : 0.0f;
+      const float incl = wave_scan_incl(dd, lane);
+      const float excl = (incl - dd) + carry_dd;
+      carry_dd += __shfl(incl, 63, 64);
+      const float alpha = 1.0f - expf(-dd);
+      const float T = expf(-excl);
+      float w = in ? nan_to_num_f(alpha * T) : 0.0f;
+      if (in && io.weights) io.weights[sbase + i] = w;
+      // median depth: first index whose inclusive cumulative weight reaches 0.5
+      const float cw = wave_scan_incl(w, lane) + carry_w;
+      carry_w = __shfl(cw, 63, 64);
+      if (median_idx < 0) {
+        const unsigned long long hit = __ballot(in && cw >= 0.5f);
+        if (hit) median_idx = base + (int)__builtin_ctzll(hit);
+      }
+      acc += w;
+      if (in) {
+        const long long o3 = (sbase + i) * 3;
+        float r = io.color[o3 + 0], g = io.color[o3 + 1], b = io.color[o3 + 2];
+        if (eval_mode) { r = nan_to_num_f(r); g = nan_to_num_f(g); b = nan_to_num_f(b); }
+        c0 += w * r; c1 += w * g; c2 += w * b;
+        if (io.diff) {
+          float x = io.diff[o3 + 0], y = io.diff[o3 + 1], z = io.diff[o3 + 2];
+          if (eval_mode) { x = nan_to_num_f(x); y = nan_to_num_f(y); z = nan_to_num_f(z); }
+          d0 += w * x; d1 += w * y; d2 += w * z;
+        }
+        if (io.tint) {
+          float x = io.tint[o3 + 0], y = io.tint[o3 + 1], z = io.tint[o3 + 2];
+          if (eval_mode) { x = nan_to_num_f(x); y = nan_to_num_f(y); z = nan_to_num_f(z); }
+          t0s += w * x; t1s += w * y; t2s += w * z;
+        }
+        if (io.pred_normals) {
+          n0 += w * io.pred_normals[o3 + 0]; n1 += w * io.pred_normals[o3 + 1]; n2 += w * io.pred_normals[o3 + 2];
+        }
+        if (io.roughness) rs += w * io.roughness[sbase + i];
+      }
+    }
+    acc = wave_sum(acc);
+    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+    if (io.diff) { d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2); }
+    if (io.tint) { t0s = wave_sum(t0s); t1s = wave_sum(t1s); t2s = wave_sum(t2s); }
+    if (io.pred_normals) { n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2); }
+    if (io.roughness) rs = wave_sum(rs);
+    if (lane == 0) {
+      const float rem = 1.0f - acc;
+      float bg0 = 0.0f, bg1 = 0.0f, bg2 = 0.0f;
+      if (background == 1) { bg0 = bg1 = bg2 = 1.0f; }
+      if (background == 2) { bg0 = io.bg_rgb[ray * 3 + 0]; bg1 = io.bg_rgb[ray * 3 + 1]; bg2 = io.bg_rgb[ray * 3 + 2]; }
+      if (background != 0) { c0 = c0 + bg0 * rem; c1 = c1 + bg1 * rem; c2 = c2 + bg2 * rem; }
+      if (io.rgb) {  // eval: renderer clamp; CLIP_RGB: the model's own clip(0,1) -- same clamp
+        if (clip_rgb) {
+          c0 = fminf(fmaxf(c0, 0.0f), 1.0f); c1 = fminf(fmaxf(c1, 0.0f), 1.0f); c2 = fminf(fmaxf(c2, 0.0f), 1.0f);
+        }
+        io.rgb[ray * 3 + 0] = c0; io.rgb[ray * 3 + 1] = c1; io.rgb[ray * 3 + 2] = c2;
+      }
+      if (io.accumulation) io.accumulation[ray] = acc;
+      if (io.depth) {
+        int mi = median_idx < 0 ? S - 1 : median_idx;
+        io.depth[ray] = (bins[mi] + bins[mi + 1]) / 2.0f;
+      }
+      if (io.diff_out) {  // renderer_rgb: white background (reflect_sampling_nerf_model.py:215)
+        float x = d0 + rem, y = d1 + rem, z = d2 + rem;
+        if (eval_mode) { x = fminf(fmaxf(x, 0.0f), 1.0f); y = fminf(fmaxf(y, 0.0f), 1.0f); z = fminf(fmaxf(z, 0.0f), 1.0f); }
+        io.diff_out[ray * 3 + 0] = x; io.diff_out[ray * 3 + 1] = y; io.diff_out[ray * 3 + 2] = z;
+      }
+      if (io.tint_out) {  // renderer_factor: "random" => no background (model.py:123,217)
+        float x = t0s, y = t1s, z = t2s;
+        if (eval_mode) { x = fminf(fmaxf(x, 0.0f), 1.0f); y = fminf(fmaxf(y, 0.0f), 1.0f); z = fminf(fmaxf(z, 0.0f), 1.0f); }
+        io.tint_out[ray * 3 + 0] = x; io.tint_out[ray * 3 + 1] = y; io.tint_out[ray * 3 + 2] = z;
+      }
+      if (io.normals_out) {  // NormalsRenderer: n / (|n| + 1e-10)
+        const float nn = sqrtf(n0 * n0 + n1 * n1 + n2 * n2) + 1e-10f;
+        io.normals_out[ray * 3 + 0] = n0 / nn; io.normals_out[ray * 3 + 1] = n1 / nn; io.normals_out[ray * 3 + 2] = n2 / nn;
+      }
+      if (io.roughness_out) io.roughness_out[ray] = rs;
+    }
+  }
+}
+
+extern "C" int rsn_composite(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t background,
+                             int32_t flags, const rsn_composite_io* io, void* stream) {
+  RSN_REQUIRE(io, RSN_ERR_INVALID_ARGUMENT, "io is NULL");
+  RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
+  RSN_REQUIRE(background >= 0 && background <= 2, RSN_ERR_INVALID_ARGUMENT, "background=%d", background);
+  if (n_rays == 0) return RSN_OK;
+  RSN_REQUIRE(io->sigma && io->euclid_bins && io->color, RSN_ERR_INVALID_ARGUMENT, "sigma/bins/color is NULL");
+  RSN_REQUIRE(background != 2 || io->bg_rgb, RSN_ERR_INVALID_ARGUMENT, "background=2 needs bg_rgb");
+  RSN_REQUIRE((!io->diff_out || io->diff) && (!io->tint_out || io->tint) && (!io->normals_out || io->pred_normals) &&
+                  (!io->roughness_out || io->roughness),
+              RSN_ERR_INVALID_ARGUMENT, "a surface-attribute output is requested without its per-sample input");
+  int blocks = (n_rays + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rsn_composite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_rays, n_dev, n_samples,
+                     background, flags, *io);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reflection rays: mask, stable compaction, secondary-ray construction (model.py:222-229,240-241,267-289).
+// A single 1024-thread workgroup walks the rays in order (block scan per 1024-ray chunk) so the
+// compaction is stable like the reference's boolean-mask gather.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rsn_reflect_setup_kernel(int R, float reflect_far, const rsn_reflect_io io) {
+  __shared__ int s_wave_tot[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int start = 0; start < R; start += 1024) {
+    const int r = start + tid;
+    bool mk = false;
+    float ndd = 0.0f, accv = 0.0f;
+    float d[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (r < R) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { d[c] = io.directions[r * 3 + c]; n[c] = io.pred_normals[r * 3 + c]; }
+      ndd = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+      accv = io.accumulation[r];
+      mk = (accv > 1e-2f) && (ndd < 0.0f);
+      io.mask[r] = mk ? 1 : 0;
+      if (io.n_dot_d) io.n_dot_d[r] = ndd;
+      const float dflt = 1.0f * (1.0f - accv);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { io.reflect_coarse[r * 3 + c] = dflt; io.reflect_fine[r * 3 + c] = dflt; }
+    }
+    const unsigned long long bal = __ballot(mk);
+    const int in_wave = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_tot[wid] = __builtin_popcountll(bal);
+    __syncthreads();
+    int wave_off = 0, chunk_tot = 0;
+    for (int wv = 0; wv < 16; ++wv) {
+      const int t = s_wave_tot[wv];
+      if (wv < wid) wave_off += t;
+      chunk_tot += t;
+    }
+    const int base = s_base;
+    if (mk) {
+      const int i = base + wave_off + in_wave;
+      io.ray_index[i] = r;
+      const float dep = io.depth[r];
+      float rf[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        io.origins2[i * 3 + c] = io.origins[r * 3 + c] + dep * d[c];
+        rf[c] = d[c] - 2.0f * ndd * n[c];
+      }
+      const float nrm = fmaxf(sqrtf(rf[0] * rf[0] + rf[1] * rf[1] + rf[2] * rf[2]), 1e-12f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) io.directions2[i * 3 + c] = rf[c] / nrm;
+      const float rough = io.roughness[r];
+      const float sq = 2.0f * fabsf(ndd) * (rough * rough);
+      io.sqradius[i] = sq;
+      io.pixel_area2[i] = 3.141592653589793f * sq;
+      io.nears2[i] = 0.0f;  // zeros_like(nears) * self.near == 0 (reflect_sampling_nerf_model.py:287)
+      io.fars2[i] = reflect_far;
+    }
+    __syncthreads();
+    if (tid == 0) s_base = base + chunk_tot;
+    __syncthreads();
+  }
+  if (tid == 0) *io.n_masked = s_base;
+}
+
+extern "C" int rsn_reflect_setup(int32_t n_rays, float reflect_far, const rsn_reflect_io* io, void* stream) {
+  RSN_REQUIRE(io, RSN_ERR_INVALID_ARGUMENT, "io is NULL");
+  RSN_REQUIRE(n_rays >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
+  RSN_REQUIRE(io->n_masked, RSN_ERR_INVALID_ARGUMENT, "n_masked is NULL");
+  RSN_REQUIRE(n_rays == 0 || (io->origins && io->directions && io->accumulation && io->depth && io->pred_normals &&
+                              io->roughness && io->mask && io->ray_index && io->origins2 && io->directions2 &&
+                              io->sqradius && io->pixel_area2 && io->nears2 && io->fars2 && io->reflect_coarse &&
+                              io->reflect_fine),
+              RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  hipLaunchKernelGGL(rsn_reflect_setup_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_rays, reflect_far, *io);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+__global__ void rsn_reflect_combine_kernel(int n_max, const int* n_masked, const int* ray_index, const float* diff,
+                                           const float* tint, const float* comp, float* out) {
+  const int M = dyn_count(n_max, n_masked);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * 3) return;
+  const int i = e / 3, c = e - i * 3;
+  const int r = ray_index[i];
+  const float v = diff[r * 3 + c] + tint[r * 3 + c] * comp[i * 3 + c];
+  out[r * 3 + c] = fminf(fmaxf(v, 0.0f), 1.0f);
+}
+
+extern "C" int rsn_reflect_combine(int32_t n_rays_max, const int32_t* n_masked, const int32_t* ray_index,
+                                   const float* diff, const float* tint, const float* comp, float* out, void* stream) {
+  RSN_REQUIRE(n_rays_max >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays_max=%d", n_rays_max);
+  if (n_rays_max == 0) return RSN_OK;
+  RSN_REQUIRE(n_masked && ray_index && diff && tint && comp && out, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  const int threads = 256;
+  const int blocks = (n_rays_max * 3 + threads - 1) / threads;
+  hipLaunchKernelGGL(rsn_reflect_combine_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_rays_max,
+                     n_masked, ray_index, diff, tint, comp, out);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}

@@ -1,0 +1,117 @@
+"""Thin torch-facing wrappers over the C ABI (include/rsn.h).  torch is plumbing here: it owns device
+memory and the stream; every arithmetic step runs in librsn_hip.so.  No fallbacks."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _abi
+from ._abi import CompositeIO, FieldOutputs, ReflectIO, check, ptr
+
+RSN_COMP_EVAL = 1
+RSN_COMP_CLIP_RGB = 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.contiguous().float()
+    if not t.is_cuda:
+        raise _abi.RsnError("the HIP path needs tensors on a cuda (ROCm) device; there is no CPU fallback")
+    return t
+
+
+def sample_spaced(n_rays: int, n_dev: Optional[Tensor], n_samples: int, spacing: int, tan: float, nears: Tensor,
+                  fars: Tensor, t_rand: Optional[Tensor]):
+    lib = _abi.load_library()
+    sb = torch.empty(n_rays, n_samples + 1, device=nears.device, dtype=torch.float32)
+    eb = torch.empty_like(sb)
+    if t_rand is not None:
+        t_rand = _f32c(t_rand)
+    check(lib.rsn_sample_spaced(n_rays, ptr(n_dev), n_samples, spacing, tan, ptr(nears), ptr(fars), ptr(t_rand),
+                                ptr(sb), ptr(eb), _stream()))
+    return sb, eb
+
+
+def sample_pdf(n_rays: int, n_dev: Optional[Tensor], s_in: int, s_out: int, spacing: int, tan: float,
+               histogram_padding: float, nears: Tensor, fars: Tensor, weights: Tensor, spacing_bins_in: Tensor,
+               u_rand: Optional[Tensor]):
+    lib = _abi.load_library()
+    sb = torch.empty(n_rays, s_out + 1, device=nears.device, dtype=torch.float32)
+    eb = torch.empty_like(sb)
+    if u_rand is not None:
+        u_rand = _f32c(u_rand)
+    check(lib.rsn_sample_pdf(n_rays, ptr(n_dev), s_in, s_out, spacing, tan, histogram_padding, ptr(nears), ptr(fars),
+                             ptr(weights), ptr(spacing_bins_in), ptr(u_rand), ptr(sb), ptr(eb), _stream()))
+    return sb, eb
+
+
+def composite(n_rays: int, n_dev: Optional[Tensor], n_samples: int, background: int, flags: int, sigma: Tensor,
+              euclid_bins: Tensor, color: Tensor, bg_rgb: Optional[Tensor] = None, level: Optional[Dict] = None,
+              surface: bool = False, want_depth: bool = True) -> Dict[str, Tensor]:
+    """-> weights [R,S], rgb [R,3], accumulation [R], depth [R] (+ diff/tint/normals/roughness if surface)."""
+    lib = _abi.load_library()
+    dev = sigma.device
+    out = {
+        "weights": torch.empty(n_rays, n_samples, device=dev, dtype=torch.float32),
+        "rgb": torch.empty(n_rays, 3, device=dev, dtype=torch.float32),
+        "accumulation": torch.empty(n_rays, device=dev, dtype=torch.float32),
+    }
+    if want_depth:
+        out["depth"] = torch.empty(n_rays, device=dev, dtype=torch.float32)
+    io = CompositeIO()
+    io.sigma, io.euclid_bins, io.color, io.bg_rgb = ptr(sigma), ptr(euclid_bins), ptr(color), ptr(bg_rgb)
+    io.weights, io.rgb, io.accumulation = ptr(out["weights"]), ptr(out["rgb"]), ptr(out["accumulation"])
+    io.depth = ptr(out.get("depth"))
+    if surface:
+        assert level is not None
+        out["diff"] = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
+        out["tint"] = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
+        out["normals"] = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
+        out["roughness"] = torch.empty(n_rays, device=dev, dtype=torch.float32)
+        io.diff, io.tint = ptr(level["diff"]), ptr(level["tint"])
+        io.pred_normals, io.roughness = ptr(level["pred_normals"]), ptr(level["roughness"])
+        io.diff_out, io.tint_out = ptr(out["diff"]), ptr(out["tint"])
+        io.normals_out, io.roughness_out = ptr(out["normals"]), ptr(out["roughness"])
+    check(lib.rsn_composite(n_rays, ptr(n_dev), n_samples, background, flags, io, _stream()))
+    return out
+
+
+def reflect_setup(origins: Tensor, directions: Tensor, accumulation: Tensor, depth: Tensor, normals: Tensor,
+                  roughness: Tensor, reflect_far: float) -> Dict[str, Tensor]:
+    lib = _abi.load_library()
+    R, dev = origins.shape[0], origins.device
+    f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+    out = {
+        "mask": torch.empty(R, device=dev, dtype=torch.uint8),
+        "n_masked": torch.zeros(1, device=dev, dtype=torch.int32),
+        "ray_index": torch.empty(R, device=dev, dtype=torch.int32),
+        "n_dot_d": f(R), "origins2": f(R, 3), "directions2": f(R, 3), "sqradius": f(R), "pixel_area2": f(R),
+        "nears2": f(R), "fars2": f(R), "reflect_coarse": f(R, 3), "reflect_fine": f(R, 3),
+    }
+    io = ReflectIO()
+    io.origins, io.directions, io.accumulation, io.depth = ptr(origins), ptr(directions), ptr(accumulation), ptr(depth)
+    io.pred_normals, io.roughness = ptr(normals), ptr(roughness)
+    for k, v in out.items():
+        setattr(io, k, ptr(v))
+    check(lib.rsn_reflect_setup(R, reflect_far, io, _stream()))
+    return out
+
+
+def reflect_combine(n_max: int, n_masked: Tensor, ray_index: Tensor, diff: Tensor, tint: Tensor, comp: Tensor,
+                    out: Tensor) -> None:
+    lib = _abi.load_library()
+    check(lib.rsn_reflect_combine(n_max, ptr(n_masked), ptr(ray_index), ptr(diff), ptr(tint), ptr(comp), ptr(out),
+                                  _stream()))
+
+
+def field_outputs_struct(level: Dict[str, Tensor]) -> FieldOutputs:
+    fo = FieldOutputs()
+    for name in ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density"):
+        setattr(fo, name, ptr(level.get(name)))
+    return fo

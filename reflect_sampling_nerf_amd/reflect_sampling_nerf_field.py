@@ -1,0 +1,236 @@
+"""ReflectSamplingNeRFNerfField on MI355X: same constructor knobs, parameter names and method names as
+the reference Field (reflect_sampling_nerf_field.py:28-207), evaluated by the fused HIP kernels of
+librsn_hip.so instead of eager torch ops.
+
+Parameter layout / names (state_dict interchange with the reference):
+    mlp_base.layers.{i}.{weight,bias}, field_output_density.net.*, field_output_low.net.* (unused, kept),
+    field_output_bottleneck.net.*, mlp_mid.layers.0.*, field_output_mid.net.*, field_output_normals.net.*,
+    field_output_roughness.net.*, field_output_diff.net.*, field_output_tint.net.*
+Modules are created in the reference's order so that the same torch seed gives the same random init.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _abi, ops
+from ._abi import FieldDesc, FieldParams, check, ptr
+from .nerfstudio_compat import Field
+from .reflect_sampling_nerf_components import IntegratedSHEncoding, NeRFEncoding
+
+
+class _MLP(nn.Module):
+    """Parameter container shaped like nerfstudio's MLP (`.layers` ModuleList of nn.Linear)."""
+
+    def __init__(self, in_dim: int, num_layers: int, layer_width: int, skip_connections: Tuple[int, ...] = ()):
+        super().__init__()
+        self.in_dim, self.num_layers, self.layer_width = in_dim, num_layers, layer_width
+        self.out_dim = layer_width
+        skips = set(skip_connections or ())
+        layers = []
+        if num_layers == 1:
+            layers.append(nn.Linear(in_dim, layer_width))
+        else:
+            for i in range(num_layers - 1):
+                if i == 0:
+                    assert i not in skips, "Skip connection at layer 0 doesn't make sense."
+                    layers.append(nn.Linear(in_dim, layer_width))
+                elif i in skips:
+                    layers.append(nn.Linear(layer_width + in_dim, layer_width))
+                else:
+                    layers.append(nn.Linear(layer_width, layer_width))
+            layers.append(nn.Linear(layer_width, layer_width))
+        self.layers = nn.ModuleList(layers)
+
+    def get_out_dim(self) -> int:
+        return self.out_dim
+
+
+class _Head(nn.Module):
+    """Parameter container shaped like nerfstudio's FieldHead (`.net` nn.Linear)."""
+
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.net = nn.Linear(in_dim, out_dim)
+
+
+class ReflectSamplingNeRFNerfField(Field):
+    def __init__(
+        self,
+        position_encoding=None,
+        direction_encoding=None,
+        base_mlp_num_layers: int = 8,
+        base_mlp_layer_width: int = 256,
+        skip_connections: Tuple[int, ...] = (4,),
+        head_mlp_num_layers: int = 1,
+        head_mlp_layer_width: int = 128,
+        spatial_distortion=None,
+        density_bias: float = 0.5,
+        roughness_bias: float = -1.0,
+    ) -> None:
+        super().__init__()
+        self.position_encoding = position_encoding if position_encoding is not None else NeRFEncoding()
+        self.direction_encoding = direction_encoding if direction_encoding is not None else IntegratedSHEncoding()
+        pe = self.position_encoding
+        if (getattr(pe, "num_frequencies", None) != 16 or pe.get_out_dim() != 99
+                or float(getattr(pe, "min_freq", 0.0)) != 0.0):
+            raise NotImplementedError("the HIP field kernel fuses NeRFEncoding(3, 16, 0.0, max, include_input=True)")
+        if self.direction_encoding.get_out_dim() != 34:
+            raise NotImplementedError("the HIP field kernel fuses the 34-channel IntegratedSHEncoding")
+        if spatial_distortion is not None:
+            raise NotImplementedError("spatial_distortion is None in the reference model (model.py:103-106)")
+        if head_mlp_num_layers != 1:
+            raise NotImplementedError("head_mlp_num_layers != 1 is not fused (reference default: 1)")
+        self.spatial_distortion = None
+        self.skip_connections = tuple(skip_connections or ())
+        if len([s for s in self.skip_connections if 0 < s <= base_mlp_num_layers - 1]) > 1:
+            raise NotImplementedError("at most one live skip connection is fused")
+
+        W = base_mlp_layer_width
+        # creation order == reference field.py:54-86
+        self.mlp_base = _MLP(99, base_mlp_num_layers, W, self.skip_connections)
+        self.field_output_density = _Head(W, 1)
+        self.density_bias = density_bias
+        self.field_output_low = _Head(W, 3)  # never evaluated by the model (field.py:67), kept for state_dict parity
+        self.field_output_bottleneck = _Head(W, W)
+        self.mlp_mid = _MLP(34 + W, head_mlp_num_layers, head_mlp_layer_width)
+        self.field_output_mid = _Head(head_mlp_layer_width, 3)
+        self.field_output_normals = _Head(W, 3)
+        self.field_output_roughness = _Head(W, 1)
+        self.roughness_bias = roughness_bias  # stored, never applied (field.py:82)
+        self.field_output_diff = _Head(W, 3)
+        self.field_output_tint = _Head(W, 3)
+
+        self._packed: Optional[Tensor] = None
+        self._packed_key = None
+        self._desc: Optional[FieldDesc] = None
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    @property
+    def width(self) -> int:
+        return self.mlp_base.layer_width
+
+    def field_desc(self) -> FieldDesc:
+        if self._desc is None:
+            L = self.mlp_base.num_layers
+            live = [s for s in self.skip_connections if 0 < s <= L - 1]
+            d = FieldDesc()
+            d.num_layers = L
+            d.width = self.width
+            d.skip_layer = live[0] if live else -1
+            d.mid_width = self.mlp_mid.layer_width
+            d.density_bias = float(self.density_bias)
+            pe = self.position_encoding
+            freqs = 2 ** torch.linspace(float(pe.min_freq), float(pe.max_freq), int(pe.num_frequencies))
+            for i in range(16):
+                d.freqs[i] = float(freqs[i])
+            self._desc = d
+        return self._desc
+
+    def _param_struct(self) -> FieldParams:
+        p = FieldParams()
+        for i, layer in enumerate(self.mlp_base.layers):
+            p.trunk_w[i] = layer.weight.data_ptr()
+            p.trunk_b[i] = layer.bias.data_ptr()
+        for name, mod in (("density", self.field_output_density.net), ("normals", self.field_output_normals.net),
+                          ("roughness", self.field_output_roughness.net), ("diff", self.field_output_diff.net),
+                          ("tint", self.field_output_tint.net), ("bottleneck", self.field_output_bottleneck.net),
+                          ("mid", self.mlp_mid.layers[0]), ("rgb", self.field_output_mid.net)):
+            setattr(p, name + "_w", mod.weight.data_ptr())
+            setattr(p, name + "_b", mod.bias.data_ptr())
+        return p
+
+    def packed_weights(self) -> Tensor:
+        """Parameters re-laid into MFMA fragment order (rsn_pack_weights); re-packed only when a parameter
+        changed (torch bumps Tensor._version on every in-place optimiser update)."""
+        params = [p for p in self.parameters()]
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise _abi.RsnError("the Field must live on a cuda (ROCm) device: there is no CPU fallback")
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise _abi.RsnError("Field parameters must be contiguous fp32")
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or self._packed_key != key or self._packed.device != dev:
+            lib = _abi.load_library()
+            desc = self.field_desc()
+            nbytes = lib.rsn_packed_weights_bytes(C.byref(desc))
+            if nbytes == 0:
+                check(-1)
+            if self._packed is None or self._packed.numel() * 4 != nbytes or self._packed.device != dev:
+                self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+            ps = self._param_struct()
+            check(lib.rsn_pack_weights(C.byref(desc), C.byref(ps), ptr(self._packed), nbytes, ops._stream()))
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ fused evaluation (what the Model calls)
+    def evaluate_frustums(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid_bins: Tensor,
+                          n_dev: Optional[Tensor] = None, full: bool = True) -> Dict[str, Tensor]:
+        """One sampling level.  origins/directions [R,3], pixel_area [R], euclid_bins [R,S+1] ->
+        per-sample sigma [R,S], color [R,S,3] and (full) pred_normals, n_dot_d, diff, tint, roughness."""
+        lib = _abi.load_library()
+        R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
+        dev = origins.device
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        level = {"sigma": f(R, S), "color": f(R, S, 3)}
+        if full:
+            level.update({"pred_normals": f(R, S, 3), "n_dot_d": f(R, S), "diff": f(R, S, 3), "tint": f(R, S, 3),
+                          "roughness": f(R, S)})
+        fo = ops.field_outputs_struct(level)
+        desc = self.field_desc()
+        check(lib.rsn_field_forward_frustum(C.byref(desc), ptr(self.packed_weights()), R, ptr(n_dev), S, ptr(origins),
+                                            ptr(directions), ptr(pixel_area), ptr(euclid_bins), C.byref(fo),
+                                            ops._stream()))
+        return level
+
+    def evaluate_inf(self, directions: Tensor, sqradius: Tensor, n_dev: Optional[Tensor] = None) -> Tensor:
+        """get_inf_color on M (<= len) rays: directions [R,3], sqradius [R] -> rgb [R,3]."""
+        lib = _abi.load_library()
+        R = directions.shape[0]
+        out = torch.empty(R, 3, device=directions.device, dtype=torch.float32)
+        desc = self.field_desc()
+        check(lib.rsn_field_forward_inf(C.byref(desc), ptr(self.packed_weights()), R, ptr(n_dev), ptr(directions),
+                                        ptr(sqradius), ptr(out), ops._stream()))
+        return out
+
+    def evaluate_gaussians(self, means: Tensor, cov_diag: Optional[Tensor], view_dirs: Optional[Tensor],
+                           want_embedding: bool = False) -> Dict[str, Tensor]:
+        """Granular evaluation on explicit (already contracted) Gaussians: means [N,3], cov_diag [N,3]."""
+        lib = _abi.load_library()
+        N, dev = means.shape[0], means.device
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        level = {"sigma": f(N), "color": f(N, 3), "pred_normals": f(N, 3), "n_dot_d": f(N), "diff": f(N, 3),
+                 "tint": f(N, 3), "roughness": f(N), "raw_density": f(N)}
+        emb = f(N, self.width) if want_embedding else None
+        fo = ops.field_outputs_struct(level)
+        desc = self.field_desc()
+        check(lib.rsn_field_forward_gaussians(C.byref(desc), ptr(self.packed_weights()), N, ptr(means), ptr(cov_diag),
+                                              ptr(view_dirs), C.byref(fo), ptr(emb), ops._stream()))
+        if emb is not None:
+            level["embedding"] = emb
+        return level
+
+    # ------------------------------------------------------------------ reference method names (granular API)
+    def get_density(self, mean: Tensor, cov: Optional[Tensor] = None, requires_density_grad: bool = False):
+        """field.py:122-137: (density [...,1], embedding [...,W]).  Eval-mode forward only; the analytic-normal
+        path (requires_density_grad in training) is served by the fused level kernels, not here."""
+        if requires_density_grad and self.training:
+            raise NotImplementedError("training-mode density gradients are only available through the fused path")
+        shp = mean.shape[:-1]
+        m = ops._f32c(mean.reshape(-1, 3))
+        cd = None
+        if cov is not None:
+            cd = ops._f32c(torch.diagonal(cov, dim1=-2, dim2=-1).reshape(-1, 3))
+        lv = self.evaluate_gaussians(m, cd, None, want_embedding=True)
+        self._last_level = {k: v.reshape(*shp, -1) for k, v in lv.items()}
+        return self._last_level["sigma"], self._last_level["embedding"]
+
+    def get_inf_color(self, directions: Tensor, sqradius: Tensor) -> Tensor:
+        """field.py:190-201."""
+        shp = directions.shape[:-1]
+        out = self.evaluate_inf(ops._f32c(directions.reshape(-1, 3)), ops._f32c(sqradius.reshape(-1)))
+        return out.reshape(*shp, 3)

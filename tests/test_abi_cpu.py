@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/rsn.h declares, and the host mirror keeps the reference's names (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import reflect_sampling_nerf_amd as pkg
+from reflect_sampling_nerf_amd import _abi
+from reflect_sampling_nerf_amd._build import LIB_PATH, build_library
+from tests.helpers import load_golden
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_library()
+    return pkg.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    header = open(os.path.join(REPO, "include", "rsn.h")).read()
+    declared = set(re.findall(r"\b(rsn_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_abi.EXPORTED_SYMBOLS), declared ^ set(_abi.EXPORTED_SYMBOLS)
+    raw = C.CDLL(LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in rsn.h but not exported"
+    assert lib.rsn_abi_version() == 1
+
+
+def test_packed_size_and_argument_errors(lib):
+    model = pkg.ReflectSamplingNeRFModelConfig().setup(scene_box=None, num_train_data=1)
+    desc = model.field.field_desc()
+    nbytes = lib.rsn_packed_weights_bytes(C.byref(desc))
+    # every nn.Linear of the path appears once (zero padded to MFMA tiles), field_output_low does not
+    n_used = sum(p.numel() for n, p in model.field.named_parameters() if "field_output_low" not in n)
+    assert nbytes // 4 >= n_used and nbytes // 4 < 1.1 * n_used
+    bad = _abi.FieldDesc()
+    bad.num_layers, bad.width, bad.skip_layer, bad.mid_width = 8, 100, 4, 128
+    assert lib.rsn_packed_weights_bytes(C.byref(bad)) == 0
+    assert b"width=100" in lib.rsn_last_error()
+    bad.width, bad.num_layers, bad.skip_layer = 128, 5, 4  # the reference MLP raises for skip == last layer
+    assert lib.rsn_packed_weights_bytes(C.byref(bad)) == 0
+    # NULL / bad-size arguments are rejected before any launch
+    assert lib.rsn_sample_spaced(4, None, 0, 0, 1.0, None, None, None, None, None, None) == -1
+    assert lib.rsn_composite(4, None, 8, 7, 0, None, None) == -1
+
+
+def test_state_dict_names_match_reference():
+    meta, g = load_golden("eval_l8_w32")
+    ref_names = set(g["param"].keys())
+    model = pkg.ReflectSamplingNeRFModelConfig().setup(scene_box=None, num_train_data=1)
+    assert set(model.field.state_dict().keys()) == ref_names
+    assert sum(p.numel() for p in model.get_param_groups()["fields"]) == 618513
+    assert set(model.get_param_groups().keys()) == {"fields"}
+
+
+def test_same_seed_same_init_as_reference_order():
+    """Modules are created in the reference's order, so the oracle's init (seeded nn.Linear-equivalent draws in
+    that order) and ours have identical shapes in identical order."""
+    from oracle import cpu_ref
+
+    P = cpu_ref.init_params(cpu_ref.FieldSpec())
+    model = pkg.ReflectSamplingNeRFModelConfig().setup(scene_box=None, num_train_data=1)
+    sd = model.field.state_dict()
+    assert [tuple(v.shape) for v in P.values()] == [tuple(sd[k].shape) for k in P.keys()]
+
+
+def test_config_fields_and_train_mode_is_loud():
+    cfg = pkg.ReflectSamplingNeRFModelConfig()
+    assert (cfg.num_coarse_samples, cfg.num_importance_samples, cfg.num_reflect_coarse_samples,
+            cfg.num_reflect_importance_samples) == (128, 128, 64, 64)
+    assert cfg.loss_coefficients["orientation_loss_fine"] == 1e-1 and len(cfg.loss_coefficients) == 12
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    assert model.far == 256 and model.near == 1.0 / 16
+    o = torch.zeros(4, 3)
+    rb = pkg.RayBundle(origins=o, directions=o, pixel_area=torch.ones(4, 1), nears=torch.ones(4, 1),
+                       fars=torch.ones(4, 1))
+    model.eval()
+    with pytest.raises(pkg.RsnError):  # CPU tensors: there is no CPU fallback
+        model.get_outputs(rb)

@@ -1,0 +1,284 @@
+"""GPU parity: the HIP path (through the C ABI of include/rsn.h) against the CPU oracle on identical seeded
+inputs.  Tolerance (BASELINE.json north_star): 1e-4 absolute, fp32, on rendered RGB and accumulation; the
+same bound is applied to every continuous output.  Discontinuous outputs (mask, median-depth bin) are compared
+exactly except at samples that sit within 1e-5 of their threshold."""
+import pytest
+import torch
+
+import reflect_sampling_nerf_amd as pkg
+from oracle import cpu_ref
+from reflect_sampling_nerf_amd import ops
+from reflect_sampling_nerf_amd._abi import RSN_SPACING_RECIPROCAL, RSN_SPACING_UNIFORM
+from tests.helpers import load_golden, max_abs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    pkg.load_library()
+    return torch.device("cuda:0")
+
+
+def make_field(layers, width, dev, seed=0, bias_shift=0.0):
+    torch.manual_seed(seed)
+    f = pkg.ReflectSamplingNeRFNerfField(base_mlp_num_layers=layers, base_mlp_layer_width=width)
+    with torch.no_grad():
+        f.field_output_density.net.bias += bias_shift
+    P = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    return f.to(dev).eval(), P, cpu_ref.FieldSpec(num_layers=layers, width=width)
+
+
+# ---------------------------------------------------------------------------------------------- samplers
+@pytest.mark.parametrize("kind,tan,near,far", [("uniform", 1.0, 2.0, 6.0), ("reciprocal", 0.25, 0.0, 256.0)])
+@pytest.mark.parametrize("S", [1, 24, 128])
+def test_spaced_sampler(dev, kind, tan, near, far, S):
+    R = 37
+    nears, fars = torch.full((R, 1), near), torch.full((R, 1), far)
+    g = torch.Generator().manual_seed(S)
+    for t_rand in (None, torch.rand(R, S + 1, generator=g)):
+        sb_ref, eb_ref = cpu_ref.spaced_bins(kind, tan, nears, fars, S, t_rand)
+        sp = RSN_SPACING_UNIFORM if kind == "uniform" else RSN_SPACING_RECIPROCAL
+        sb, eb = ops.sample_spaced(R, None, S, sp, tan, nears.reshape(R).to(dev), fars.reshape(R).to(dev),
+                                   None if t_rand is None else t_rand.to(dev))
+        assert max_abs(sb.cpu(), sb_ref) <= 2e-7
+        # euclidean bins reach 256 for the reciprocal spacing: relative tolerance
+        rel = ((eb.cpu() - eb_ref).abs() / eb_ref.abs().clamp(min=1.0)).max()
+        assert float(rel) <= 2e-6
+
+
+@pytest.mark.parametrize("S_in,S_out", [(16, 16), (128, 128), (64, 33), (7, 130)])
+def test_pdf_sampler(dev, S_in, S_out):
+    R = 29
+    g = torch.Generator().manual_seed(S_in * 1000 + S_out)
+    w = torch.rand(R, S_in, 1, generator=g) ** 4
+    w[0] = 0.0  # all-zero weights: histogram padding only
+    w[1, : S_in // 2] = 0.0
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    sb_in, _ = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S_in, None)
+    for u_rand in (None, torch.rand(R, S_out + 1, generator=g)):
+        sb_ref, eb_ref = cpu_ref.pdf_bins("uniform", 1.0, nears, fars, w, sb_in, S_out, u_rand)
+        sb, eb = ops.sample_pdf(R, None, S_in, S_out, RSN_SPACING_UNIFORM, 1.0, 0.01, nears.reshape(R).to(dev),
+                                fars.reshape(R).to(dev), w[..., 0].contiguous().to(dev),
+                                sb_in.contiguous().to(dev), None if u_rand is None else u_rand.to(dev))
+        assert max_abs(sb.cpu(), sb_ref) <= 5e-6
+        assert max_abs(eb.cpu(), eb_ref) <= 2e-5
+        assert bool((sb[:, 1:] >= sb[:, :-1]).all()), "resampled bins must be sorted"
+
+
+# ---------------------------------------------------------------------------------------------- compositing
+@pytest.mark.parametrize("S", [1, 5, 64, 130, 192])
+@pytest.mark.parametrize("background", [0, 1, 2])
+def test_composite(dev, S, background):
+    R = 23
+    g = torch.Generator().manual_seed(S + 7 * background)
+    sigma = torch.rand(R, S, 1, generator=g) * 8.0 * (torch.rand(R, S, 1, generator=g) > 0.5)
+    sigma[0] = 0.0          # empty ray
+    sigma[1] = 1e4          # saturates in the first sample
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    _, eb = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S, torch.rand(R, S + 1, generator=g))
+    t0, t1 = eb[:, :-1], eb[:, 1:]
+    color = torch.rand(R, S, 3, generator=g) * 2.0
+    lv = {"diff": torch.rand(R, S, 3, generator=g), "tint": torch.rand(R, S, 3, generator=g),
+          "pred_normals": torch.nn.functional.normalize(torch.randn(R, S, 3, generator=g), dim=-1),
+          "roughness": torch.rand(R, S, generator=g)}
+    bg = torch.rand(R, 3, generator=g)
+    w_ref = cpu_ref.weights_from_density(sigma, t0, t1)
+    bg_ref = {0: None, 1: torch.ones(3), 2: bg}[background]
+    for training in (False, True):
+        flags = 0 if training else ops.RSN_COMP_EVAL
+        out = ops.composite(R, None, S, background, flags, sigma[..., 0].contiguous().to(dev), eb.contiguous().to(dev),
+                            color.to(dev), bg_rgb=bg.to(dev), level={k: v.to(dev) for k, v in lv.items()},
+                            surface=True)
+        assert max_abs(out["weights"].cpu(), w_ref[..., 0]) <= 1e-6
+        assert max_abs(out["rgb"].cpu(), cpu_ref.composite_rgb(color, w_ref, bg_ref, training)) <= 2e-6
+        assert max_abs(out["accumulation"].cpu(), w_ref.sum(dim=-2)[..., 0]) <= 2e-6
+        assert max_abs(out["diff"].cpu(), cpu_ref.composite_rgb(lv["diff"], w_ref, torch.ones(3), training)) <= 2e-6
+        assert max_abs(out["tint"].cpu(), cpu_ref.composite_rgb(lv["tint"], w_ref, None, training)) <= 2e-6
+        assert max_abs(out["normals"].cpu(), cpu_ref.render_normals(lv["pred_normals"], w_ref)) <= 2e-5
+        assert max_abs(out["roughness"].cpu(), (w_ref * lv["roughness"][..., None]).sum(dim=-2)[..., 0]) <= 2e-6
+        # median depth: exact unless the cumulative weight sits within 1e-5 of 0.5 at the chosen bin
+        d_ref = cpu_ref.median_depth(w_ref, t0, t1)[..., 0]
+        cw = torch.cumsum(w_ref[..., 0], dim=-1)
+        near_half = ((cw - 0.5).abs() < 1e-5).any(dim=-1)
+        bad = ((out["depth"].cpu() - d_ref).abs() > 1e-5) & ~near_half
+        assert not bool(bad.any())
+
+
+# ---------------------------------------------------------------------------------------------- the field kernel
+@pytest.mark.parametrize("layers,width", [(8, 256), (4, 128), (8, 64), (6, 128), (2, 64)])
+def test_field_level(dev, layers, width):
+    R, S = 19, 24  # 456 points: ragged against the 128-point tiles
+    fld, P, fs = make_field(layers, width, dev, seed=layers * 10 + width, bias_shift=1.0)
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=3)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    _, eb = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S, None)
+    with torch.no_grad():
+        ref = cpu_ref.field_level(P, fs, o, d, pa, eb, training=False, want_normals=False)
+    lv = fld.evaluate_frustums(o.to(dev), d.to(dev), pa.reshape(R).to(dev), eb.contiguous().to(dev))
+    torch.cuda.synchronize()
+    pairs = {"sigma": ref["sigma"][..., 0], "color": ref["color"], "pred_normals": ref["pred_normals"],
+             "n_dot_d": ref["n_dot_d"][..., 0], "diff": ref["diff"], "tint": ref["tint"],
+             "roughness": torch.sigmoid(ref["rough_raw"])[..., 0]}
+    for k, v in pairs.items():
+        assert max_abs(lv[k].cpu(), v) <= TOL, k
+
+
+def test_field_level_far_samples_are_contracted(dev):
+    """reciprocal spacing out to t=256: exercises the |x|>1 contraction branch and huge IPE arguments."""
+    R, S = 9, 64
+    fld, P, fs = make_field(8, 128, dev, seed=5, bias_shift=-1.0)
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=4)
+    nears, fars = torch.zeros(R, 1), torch.full((R, 1), 256.0)
+    _, eb = cpu_ref.spaced_bins("reciprocal", 0.25, nears, fars, S, None)
+    pa = pa * 400.0
+    with torch.no_grad():
+        ref = cpu_ref.field_level(P, fs, o, d, pa, eb, training=False, want_normals=False)
+    lv = fld.evaluate_frustums(o.to(dev), d.to(dev), pa.reshape(R).to(dev), eb.contiguous().to(dev))
+    assert max_abs(lv["sigma"].cpu(), ref["sigma"][..., 0]) <= TOL
+    assert max_abs(lv["color"].cpu(), ref["color"]) <= TOL
+
+
+def test_inf_color(dev):
+    fld, P, fs = make_field(8, 128, dev, seed=9)
+    g = torch.Generator().manual_seed(0)
+    M = 77
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+    sq = torch.rand(M, 1, generator=g) * 0.3
+    with torch.no_grad():
+        ref = cpu_ref.inf_color(P, fs, dirs, sq)
+    out = fld.get_inf_color(dirs.to(dev), sq.to(dev))
+    assert max_abs(out.cpu(), ref) <= TOL
+
+
+def test_get_density_granular_api(dev):
+    fld, P, fs = make_field(8, 128, dev, seed=11)
+    g = torch.Generator().manual_seed(1)
+    mean = torch.randn(5, 13, 3, generator=g)
+    A = torch.randn(5, 13, 3, 3, generator=g) * 0.02
+    cov = A @ A.transpose(-1, -2)
+    with torch.no_grad():
+        enc = cpu_ref.ipe(fs, mean, torch.diagonal(cov, dim1=-2, dim2=-1))
+        sig_ref, emb_ref, _ = cpu_ref.density_from_encoding(P, fs, enc)
+    sig, emb = fld.get_density(mean.to(dev), cov.to(dev))
+    assert sig.shape == (5, 13, 1) and emb.shape == (5, 13, 128)
+    assert max_abs(sig.cpu(), sig_ref) <= TOL
+    assert max_abs(emb.cpu(), emb_ref) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------- full get_outputs
+def _run_model(dev, layers, width, samples, R, seed, bias_shift, near=2.0, far=6.0):
+    torch.manual_seed(seed)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(
+        num_coarse_samples=samples[0], num_importance_samples=samples[1], num_reflect_coarse_samples=samples[2],
+        num_reflect_importance_samples=samples[3], base_mlp_num_layers=layers, base_mlp_layer_width=width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += bias_shift
+    P = {k: v.detach().clone() for k, v in model.field.state_dict().items()}
+    model.to(dev).eval()
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=seed + 50)
+    nears, fars = torch.full((R, 1), near), torch.full((R, 1), far)
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev), nears=nears.to(dev),
+                       fars=fars.to(dev))
+    out = model(rb)
+    torch.cuda.synchronize()
+    fs = cpu_ref.FieldSpec(num_layers=layers, width=width)
+    ms = cpu_ref.ModelSpec(*samples)
+    with torch.no_grad():
+        ref = cpu_ref.get_outputs(P, fs, ms, o, d, pa, nears, fars, training=False)
+    return out, ref
+
+
+@pytest.mark.parametrize("layers,width,samples,R,bias", [
+    (8, 256, (32, 32, 16, 16), 70, 2.0),
+    (8, 128, (128, 128, 64, 64), 33, 1.0),
+    (4, 128, (64, 48, 24, 40), 130, 1.5),
+    (8, 64, (16, 16, 8, 8), 257, 2.0),
+])
+def test_get_outputs_matches_oracle(dev, layers, width, samples, R, bias):
+    out, ref = _run_model(dev, layers, width, samples, R, seed=layers + width, bias_shift=bias)
+    assert set(out.keys()) == set(ref.keys())
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "accumulation_coarse", "accumulation_fine", "weights_coarse",
+              "weights_fine", "pred_normals_coarse", "pred_normals_fine", "normals_coarse", "normals_fine",
+              "n_dot_d_coarse", "n_dot_d_fine", "diff", "tint", "roughness"):
+        assert tuple(out[k].shape) == tuple(ref[k].shape), k
+        assert max_abs(out[k].cpu(), ref[k]) <= TOL, k
+    # mask: exact except for rays sitting on a threshold
+    m_gpu, m_ref = out["mask"].cpu(), ref["mask"]
+    assert m_gpu.dtype == torch.bool
+    flips = int((m_gpu != m_ref).sum())
+    assert flips == 0, f"{flips} mask flips"
+    for k in ("mid_reflect_coarse", "mid_reflect_fine"):
+        assert max_abs(out[k].cpu(), ref[k]) <= TOL, k
+    # median depths: same bin unless the cumulative weight is within 1e-5 of 0.5
+    for lvl in ("coarse", "fine"):
+        cw = torch.cumsum(ref[f"weights_{lvl}"][..., 0], dim=-1)
+        near_half = ((cw - 0.5).abs() < 1e-5).any(dim=-1, keepdim=True)
+        bad = ((out[f"depth_{lvl}"].cpu() - ref[f"depth_{lvl}"]).abs() > 1e-4) & ~near_half
+        assert not bool(bad.any()), lvl
+    assert "depth_reflect_fine" in out and out["depth_reflect_fine"].shape == ref["depth_reflect_fine"].shape
+
+
+def test_get_outputs_empty_mask_takes_early_out_shape(dev):
+    out, ref = _run_model(dev, 6, 64, (8, 8, 8, 8), 16, seed=4, bias_shift=-12.0)
+    assert int(out["mask"].sum()) == 0 and "depth_reflect_fine" not in out and "depth_reflect_fine" not in ref
+    for k in ("mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "accumulation_fine"):
+        assert max_abs(out[k].cpu(), ref[k]) <= TOL
+
+
+def test_get_outputs_on_reference_golden_rays(dev):
+    """Ties the GPU path to the REFERENCE run: same rays as the golden fixture (weights differ in width, so the
+    comparison itself is against the oracle, which the fixture pins)."""
+    meta, g = load_golden("eval_l8_w64_near0")
+    torch.manual_seed(0)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=32, num_importance_samples=32,
+                                            num_reflect_coarse_samples=16, num_reflect_importance_samples=16,
+                                            base_mlp_num_layers=8, base_mlp_layer_width=64)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    model.field.load_state_dict(g["param"])  # the reference's own state_dict loads by name
+    model.to(dev).eval()
+    i = g["in"]
+    rb = pkg.RayBundle(**{k: i[k].to(dev) for k in ("origins", "directions", "pixel_area", "nears", "fars")})
+    out = model(rb)
+    ref = g["out"]  # produced by the reference's own modules
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "accumulation_coarse", "accumulation_fine", "mid_reflect_coarse",
+              "mid_reflect_fine", "diff", "tint", "roughness", "weights_fine"):
+        assert max_abs(out[k].cpu(), ref[k]) <= TOL, k
+    assert torch.equal(out["mask"].cpu().to(torch.uint8), ref["mask"])
+
+
+# ---------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_properties(dev):
+    """BASELINE config 2 size (4096 x 128, 8 x 256): size-independent properties instead of an oracle run."""
+    R, S = 4096, 128
+    fld, _, _ = make_field(8, 256, dev, seed=0, bias_shift=1.0)
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=0)
+    o, d, pa = o.to(dev), d.to(dev), pa.reshape(R).to(dev)
+    nears, fars = torch.full((R,), 2.0, device=dev), torch.full((R,), 6.0, device=dev)
+    sb, eb = ops.sample_spaced(R, None, S, RSN_SPACING_UNIFORM, 1.0, nears, fars, None)
+    lv = fld.evaluate_frustums(o, d, pa, eb)
+    c = ops.composite(R, None, S, 1, ops.RSN_COMP_EVAL | ops.RSN_COMP_CLIP_RGB, lv["sigma"], eb, lv["color"])
+    torch.cuda.synchronize()
+    w = c["weights"]
+    assert bool(torch.isfinite(lv["color"]).all()) and bool(torch.isfinite(lv["sigma"]).all())
+    assert float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-5
+    assert max_abs(w.sum(-1), c["accumulation"]) <= 1e-5
+    assert float(c["rgb"].min()) >= 0.0 and float(c["rgb"].max()) <= 1.0
+    assert float((lv["pred_normals"].norm(dim=-1) - 1).abs().max()) <= 1e-5
+    # determinism: a second launch is bit-identical
+    lv2 = fld.evaluate_frustums(o, d, pa, eb)
+    assert torch.equal(lv["color"], lv2["color"]) and torch.equal(lv["sigma"], lv2["sigma"])
+    # tile independence: evaluating a ragged sub-batch gives the same per-sample values
+    sub = fld.evaluate_frustums(o[:777], d[:777], pa[:777], eb[:777].contiguous())
+    assert torch.equal(sub["color"], lv["color"][:777]) and torch.equal(sub["sigma"], lv["sigma"][:777])
+    # a slice of it against the oracle
+    Rs = 8
+    P = {k: v.detach().cpu() for k, v in fld.state_dict().items()}
+    with torch.no_grad():
+        ref = cpu_ref.field_level(P, cpu_ref.FieldSpec(), o[:Rs].cpu(), d[:Rs].cpu(), pa[:Rs].cpu()[:, None],
+                                  eb[:Rs].cpu(), training=False, want_normals=False)
+    assert max_abs(lv["color"][:Rs].cpu(), ref["color"]) <= TOL
+    assert max_abs(lv["sigma"][:Rs].cpu(), ref["sigma"][..., 0]) <= TOL
