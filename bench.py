@@ -52,7 +52,13 @@ def cpu_baseline(args):
     """The oracle's single-level render on the host cores, bounded sample (cpu_rays x samples)."""
     from oracle import cpu_ref
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # host cores this process may use: the GPU box gives a 1-GPU job a 16-core share of a 256-core host;
+    # more threads than that only oversubscribes (measured: 256 threads = 18 rays/s)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, int(os.environ.get("RSN_CPU_THREADS", "16")))))
     fs = cpu_ref.FieldSpec(num_layers=args.layers, width=args.width)
     P = cpu_ref.init_params(fs, seed=0)
     Rc = args.cpu_rays

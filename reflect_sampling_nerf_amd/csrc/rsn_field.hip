@@ -192,6 +192,9 @@ __device__ __forceinline__ void mma4(f32x16 (&acc)[NBO], const float4 (&w)[NBO],
 }
 
 // wseg: packed segment base (global), xl: this lane's slot of the LDS slab (float4 units, stride 64 per it).
+// sched_barrier(0) pins the software pipeline: the loads of K-iteration it+1 are issued BEFORE the 32 MFMAs
+// of iteration it (hipcc otherwise sinks them to just ahead of their first use, leaving ~500 cycles of cover
+// for an L2 round trip instead of 2048).
 template <int NBO>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl, int n_it,
                                      int lane) {
@@ -205,37 +208,44 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict
   for (; it + 1 < n_it; it += 2) {
     load_w<NBO>(wb, wp, it + 1);
     bb = xl[(it + 1) * 64];
+    __builtin_amdgcn_sched_barrier(0);
     mma4<NBO>(acc, wa, ba);
+    __builtin_amdgcn_sched_barrier(0);
     if (it + 2 < n_it) {
       load_w<NBO>(wa, wp, it + 2);
       ba = xl[(it + 2) * 64];
     }
+    __builtin_amdgcn_sched_barrier(0);
     mma4<NBO>(acc, wb, bb);
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (it < n_it) mma4<NBO>(acc, wa, ba);
 }
 
+// acc[nb][4q+j] = bias[nb*32 + 8q + 4h + j]: the accumulators start from the bias (what torch's addmm does),
+// so the 4*NBO bias loads are issued back to back ahead of the K loop and the epilogue needs no memory reads.
 template <int NBO>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[NBO], const float* __restrict__ bias, int h) {
 #pragma unroll
   for (int nb = 0; nb < NBO; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
+      acc[nb][4 * q + 0] = bv.x;
+      acc[nb][4 * q + 1] = bv.y;
+      acc[nb][4 * q + 2] = bv.z;
+      acc[nb][4 * q + 3] = bv.w;
+    }
 }
 
-// X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3] + bias[nb*32 + 8q + 4h ..])
+// X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3])   (bias already inside acc, see init_acc)
 template <int NBO, int NBS, bool RELU>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], const float* __restrict__ bias, float4* xl, int h) {
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl) {
 #pragma unroll
   for (int nb = 0; nb < NBS; ++nb)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
-      float4 v;
-      v.x = acc[nb][4 * q + 0] + bv.x;
-      v.y = acc[nb][4 * q + 1] + bv.y;
-      v.z = acc[nb][4 * q + 2] + bv.z;
-      v.w = acc[nb][4 * q + 3] + bv.w;
+      float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
       if (RELU) {
         v.x = fmaxf(v.x, 0.0f);
         v.y = fmaxf(v.y, 0.0f);
@@ -344,19 +354,19 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     // ---------------- trunk -----------------
     {
       f32x16 acc[NB];
-      zero_acc<NB>(acc);
+      init_acc<NB>(acc, pk + a.L.b[0], h);
       gemm<NB>(acc, pk + a.L.w_enc0, X, RSN_ENC_ITS, lane);
-      store_act<NB, NB, true>(acc, pk + a.L.b[0], X, h);
+      store_act<NB, NB, true>(acc, X);
 #pragma unroll 1
       for (int l = 1; l < a.num_layers; ++l) {
-        zero_acc<NB>(acc);
+        init_acc<NB>(acc, pk + a.L.b[l], h);
         gemm<NB>(acc, pk + a.L.w_x[l], X, NB * 4, lane);
         if (l == a.skip_layer) {
 #pragma unroll
           for (int it = 0; it < RSN_ENC_ITS; ++it) X[it * 64] = stash[it];
           gemm<NB>(acc, pk + a.L.w_enc_skip, X, RSN_ENC_ITS, lane);
         }
-        store_act<NB, NB, true>(acc, pk + a.L.b[l], X, h);  // ReLU between layers and out_activation=ReLU
+        store_act<NB, NB, true>(acc, X);  // ReLU between layers and out_activation=ReLU
       }
     }
     if (a.embedding && valid) {
@@ -369,16 +379,10 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     float dcol[3], tcol[3], rho;
     {
       f32x16 acc[NB + 1];
-      zero_acc<NB + 1>(acc);
+      init_acc<NB + 1>(acc, pk + a.L.b_bh, h);
       gemm<NB + 1>(acc, pk + a.L.w_bh, X, NB * 4, lane);
-      const float* __restrict__ bh = pk + a.L.b_bh + W;
-      const float r0 = acc[NB][0] + bh[4 * h + 0];
-      const float r1 = acc[NB][1] + bh[4 * h + 1];
-      const float r2 = acc[NB][2] + bh[4 * h + 2];
-      const float r3 = acc[NB][3] + bh[4 * h + 3];
-      const float r4 = acc[NB][4] + bh[8 + 4 * h + 0];
-      const float r5 = acc[NB][5] + bh[8 + 4 * h + 1];
-      const float r6 = acc[NB][6] + bh[8 + 4 * h + 2];
+      const float r0 = acc[NB][0], r1 = acc[NB][1], r2 = acc[NB][2], r3 = acc[NB][3];
+      const float r4 = acc[NB][4], r5 = acc[NB][5], r6 = acc[NB][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
       const float rough_raw = __shfl(r4, m, 64);
       rho = softplus_f(rough_raw);
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         }
       }
       // bottleneck output (no activation) becomes the x-part of mlp_mid's input
-      store_act<NB + 1, NB, false>(acc, pk + a.L.b_bh, X, h);
+      store_act<NB + 1, NB, false>(acc, X);
     }
 
     // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
@@ -437,20 +441,19 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     // ---------------- mlp_mid + RGB head -----------------
     {
       f32x16 accm[4];
-      zero_acc<4>(accm);
+      init_acc<4>(accm, pk + a.L.b_mid, h);
       gemm<4>(accm, pk + a.L.w_mid_sh, AUX, RSN_SH_ITS, lane);
       gemm<4>(accm, pk + a.L.w_mid_x, X, NB * 4, lane);
-      store_act<4, 4, true>(accm, pk + a.L.b_mid, X, h);
+      store_act<4, 4, true>(accm, X);
     }
     {
       f32x16 accr[1];
-      zero_acc<1>(accr);
+      init_acc<1>(accr, pk + a.L.b_rgb, h);
       gemm<1>(accr, pk + a.L.w_rgb, X, 16, lane);
       if (h == 1 && valid) {
-        const float* __restrict__ br = pk + a.L.b_rgb;
-        const float m0 = sigmoid_f(accr[0][0] + br[4]);
-        const float m1 = sigmoid_f(accr[0][1] + br[5]);
-        const float m2 = sigmoid_f(accr[0][2] + br[6]);
+        const float m0 = sigmoid_f(accr[0][0]);
+        const float m1 = sigmoid_f(accr[0][1]);
+        const float m2 = sigmoid_f(accr[0][2]);
         if (a.out.color) {
           if (a.mode == RSN_MODE_INF) {
             a.out.color[pc * 3 + 0] = m0; a.out.color[pc * 3 + 1] = m1; a.out.color[pc * 3 + 2] = m2;

@@ -46,11 +46,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// inclusive scan across the 64 lanes of a wave
-__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+// Inclusive scan across the 64 lanes of a wave.  Accumulated in fp64 and rounded once per element, like
+// ATen's CPU cumsum (acc_type<float> = double): the prefix sums are then independent of the scan order.
+__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const float t = __shfl_up(v, off, 64);
+    const double t = __shfl_up(v, off, 64);
     if (lane >= off) v += t;
   }
   return v;
@@ -128,12 +129,12 @@ __global__ __launch_bounds__(256) void rsn_sample_pdf_kernel(int n_rays, const i
     const float padd = padding / (float)s_in;
     wsum += padding;
     // cdf = min(1, cumsum(pdf)), with a leading 0
-    float carry = 0.0f;
+    double carry = 0.0;
     for (int base = 0; base < s_in; base += 64) {
       const int i = base + lane;
       const float pdf = (i < s_in) ? ((w[i] + hist_pad) + padd) / wsum : 0.0f;
-      const float inc = wave_scan_incl(pdf, lane) + carry;
-      if (i < s_in) cdf[i + 1] = fminf(1.0f, inc);
+      const double inc = wave_scan_incl((double)pdf, lane) + carry;
+      if (i < s_in) cdf[i + 1] = fminf(1.0f, (float)inc);
       carry = __shfl(inc, 63, 64);
     }
     if (lane == 0) cdf[0] = 0.0f;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void rsn_composite_kernel(int n_rays, const in
   for (int ray = blockIdx.x * 4 + wid; ray < R; ray += gridDim.x * 4) {
     const long long sbase = (long long)ray * S;
     const float* bins = io.euclid_bins + (long long)ray * (S + 1);
-    float carry_dd = 0.0f, carry_w = 0.0f;
+    double carry_dd = 0.0, carry_w = 0.0;
     float acc = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, t0s = 0.0f, t1s = 0.0f, t2s = 0.0f;
     float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, rs = 0.0f;
@@ -220,16 +221,17 @@ __global__ __launch_bounds__(256) void rsn_composite_kernel(int n_rays, const in
         sg = io.sigma[sbase + i];
       }
       const float dd = in ? (tb - ta) * sg : 0.0f;
-      const float incl = wave_scan_incl(dd, lane);
-      const float excl = (incl - dd) + carry_dd;
+      const double incl = wave_scan_incl((double)dd, lane);
+      const float excl = (float)((incl - (double)dd) + carry_dd);
       carry_dd += __shfl(incl, 63, 64);
       const float alpha = 1.0f - expf(-dd);
       const float T = expf(-excl);
       float w = in ? nan_to_num_f(alpha * T) : 0.0f;
       if (in && io.weights) io.weights[sbase + i] = w;
       // median depth: first index whose inclusive cumulative weight reaches 0.5
-      const float cw = wave_scan_incl(w, lane) + carry_w;
-      carry_w = __shfl(cw, 63, 64);
+      const double cwd = wave_scan_incl((double)w, lane) + carry_w;
+      carry_w = __shfl(cwd, 63, 64);
+      const float cw = (float)cwd;
       if (median_idx < 0) {
         const unsigned long long hit = __ballot(in && cw >= 0.5f);
         if (hit) median_idx = base + (int)__builtin_ctzll(hit);
