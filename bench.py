@@ -194,6 +194,13 @@ def main():
             flop = FLOP_PER_SAMPLE * R * S if (args.layers, args.width) == (8, 256) else None
             if flop is not None:
                 achieved = flop / (kms * 1e-3) / 1e12
+                traffic = None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
+                try:
+                    summ = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_summary.json"))
+                    with open(os.path.join(REPO, "profiles", summ[-1])) as fh:
+                        traffic = json.load(fh).get("hbm_traffic_bytes_per_launch")
+                except (OSError, IndexError, ValueError):
+                    pass
                 line["roofline"] = {
                     "kernel": "rsn_field_kernel<8>",
                     "bound": "mfma",
@@ -201,7 +208,9 @@ def main():
                     "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s",
                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                    "traffic": None,
+                    "traffic": traffic,
+                    "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), PMC passes "
+                                    "of tools/profile_round.sh, latest profiles/*_summary.json",
                     "kernel_ms": kms,
                     "algorithmic_flop_per_launch": flop,
                 }

@@ -347,9 +347,20 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       if (h == 0) raw = make_float4(mc[0], mc[1], mc[2], 0.0f);
       X[12 * 64] = raw;
     }
-    float4 stash[RSN_ENC_ITS];  // this lane's encoded inputs, re-used by the skip layer
+    // this lane's 52 encoded inputs, re-used by the skip layer.  Held as vector-typed SSA values (not an
+    // indexable array) so that they stay in the unified VGPR/AGPR file instead of scratch memory.
+    f32x16 st0, st1, st2;
+    float4 st3;
+    {
 #pragma unroll
-    for (int it = 0; it < RSN_ENC_ITS; ++it) stash[it] = X[it * 64];
+      for (int it = 0; it < 4; ++it) {
+        const float4 t0 = X[it * 64], t1 = X[(4 + it) * 64], t2 = X[(8 + it) * 64];
+        st0[4 * it + 0] = t0.x; st0[4 * it + 1] = t0.y; st0[4 * it + 2] = t0.z; st0[4 * it + 3] = t0.w;
+        st1[4 * it + 0] = t1.x; st1[4 * it + 1] = t1.y; st1[4 * it + 2] = t1.z; st1[4 * it + 3] = t1.w;
+        st2[4 * it + 0] = t2.x; st2[4 * it + 1] = t2.y; st2[4 * it + 2] = t2.z; st2[4 * it + 3] = t2.w;
+      }
+      st3 = X[12 * 64];
+    }
 
     // ---------------- trunk -----------------
     {
@@ -363,7 +374,12 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         gemm<NB>(acc, pk + a.L.w_x[l], X, NB * 4, lane);
         if (l == a.skip_layer) {
 #pragma unroll
-          for (int it = 0; it < RSN_ENC_ITS; ++it) X[it * 64] = stash[it];
+          for (int it = 0; it < 4; ++it) {
+            X[it * 64] = make_float4(st0[4 * it], st0[4 * it + 1], st0[4 * it + 2], st0[4 * it + 3]);
+            X[(4 + it) * 64] = make_float4(st1[4 * it], st1[4 * it + 1], st1[4 * it + 2], st1[4 * it + 3]);
+            X[(8 + it) * 64] = make_float4(st2[4 * it], st2[4 * it + 1], st2[4 * it + 2], st2[4 * it + 3]);
+          }
+          X[12 * 64] = st3;
           gemm<NB>(acc, pk + a.L.w_enc_skip, X, RSN_ENC_ITS, lane);
         }
         store_act<NB, NB, true>(acc, X);  // ReLU between layers and out_activation=ReLU
