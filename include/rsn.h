@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 1
+#define RSN_ABI_VERSION 2
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -87,6 +87,19 @@ typedef struct rsn_field_outputs {
   float* raw_density;  /* [N]    density head before bias/softplus    field.py:133-135 */
 } rsn_field_outputs;
 
+/* Activations the training-mode forward keeps for the backward pass (all row-major fp32, N = n_rays*n_samples
+ * rows; W = width, L = num_layers).  Written by rsn_field_forward_frustum_train. */
+typedef struct rsn_field_saved {
+  float* enc;     /* [N,104]  encoded inputs (input of trunk layer 0), kernel slot order                   */
+  float* act;     /* [L,N,W]  post-ReLU output of trunk layer l (act[L-1] = embedding)                       */
+  float* bott;    /* [N,W]    bottleneck output                                                              */
+  float* sh;      /* [N,40]   attenuated SH-34 inputs of mlp_mid, kernel slot order                          */
+  float* hid;     /* [N,128]  mlp_mid hidden (post-ReLU)                                                     */
+  float* heads;   /* [N,8]    raw normal head (3), raw roughness head (1), mid RGB (3), pad                  */
+  float* normals; /* [N,3]    OUT: analytic normals -normalize(d raw_density/d mean) (field.py:146-147),     *
+                   *          or NULL to skip the sweep (reflect levels, model.py:295,321)                    */
+} rsn_field_saved;
+
 int rsn_abi_version(void);
 const char* rsn_last_error(void);
 
@@ -125,6 +138,14 @@ int rsn_field_forward_frustum(const rsn_field_desc* desc, const float* packed, i
                               int32_t n_samples, const float* origins, const float* directions,
                               const float* pixel_area, const float* euclid_bins, const rsn_field_outputs* out,
                               void* stream);
+
+/* Training-mode variant of rsn_field_forward_frustum: identical outputs, plus the saved activations and
+ * (when saved->normals != NULL) the analytic normals of Field.get_normals (reflect_sampling_nerf_field.py:
+ * 125-127,134-135,146-147; reflect_sampling_nerf_model.py:159-160,194-195). */
+int rsn_field_forward_frustum_train(const rsn_field_desc* desc, const float* packed, int32_t n_rays,
+                                    const int32_t* n_dev, int32_t n_samples, const float* origins,
+                                    const float* directions, const float* pixel_area, const float* euclid_bins,
+                                    const rsn_field_outputs* out, const rsn_field_saved* saved, void* stream);
 
 /* rsn_field_forward_inf: get_inf_color (reflect_sampling_nerf_field.py:190-201): mean = 2d,
  * Sigma = 0.6*sqradius*(I - d d^T), no contraction, SH inputs zeroed; out_rgb [M,3]. */

@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 1
+RSN_ABI_VERSION = 2
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -49,6 +49,10 @@ class FieldOutputs(C.Structure):
                 ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density")]
 
 
+class FieldSaved(C.Structure):
+    _fields_ = [(n, _fp) for n in ("enc", "act", "bott", "sh", "hid", "heads", "normals")]
+
+
 class CompositeIO(C.Structure):
     _fields_ = [(n, _fp) for n in
                 ("sigma", "euclid_bins", "color", "bg_rgb", "diff", "tint", "pred_normals", "roughness",
@@ -73,6 +77,9 @@ _SIGNATURES = {
                                  _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_field_forward_frustum": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp,
                                             _fp, C.POINTER(FieldOutputs), C.c_void_p]),
+    "rsn_field_forward_frustum_train": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, C.c_int32, _fp, _fp,
+                                                  _fp, _fp, C.POINTER(FieldOutputs), C.POINTER(FieldSaved),
+                                                  C.c_void_p]),
     "rsn_field_forward_inf": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_field_forward_gaussians": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp,
                                               C.POINTER(FieldOutputs), _fp, C.c_void_p]),

@@ -45,6 +45,13 @@ struct RsnPackedLayout {
   size_t w_bh, b_bh;                  // bottleneck (nb blocks) + heads (1 block)
   size_t w_mid_sh, w_mid_x, b_mid;    // mlp_mid: SH part, bottleneck part
   size_t w_rgb, b_rgb;                // field_output_mid (rows 4..6 of one block)
+  // transposed segments (training: dX sweeps).  Rows = the layer's INPUT features, K = its output features.
+  size_t wT_x[RSN_MAX_TRUNK_LAYERS];  // (x-part of layer l)^T, l >= 1: rows W, K = W
+  size_t wT_enc0, wT_enc_skip;        // (encoded-input part)^T: rows = 104 slots padded to 128, K = W
+  size_t wT_bh;                       // [bottleneck; heads]^T: rows W, K = W + 32
+  size_t wT_mid_x;                    // (bottleneck part of mlp_mid)^T: rows W, K = mid_width
+  size_t wT_rgb;                      // (RGB head)^T: rows mid_width, K = 32 (k = 4..6 live)
+  size_t v_density;                   // density head weight row [W] (seed of the analytic-normal sweep)
   size_t total;                       // floats
 };
 

@@ -44,6 +44,8 @@ struct FieldArgs {
   const float* view_dirs;
   rsn_field_outputs out;
   float* embedding;
+  rsn_field_saved saved;      // training: activations kept for the backward pass (all NULL in eval)
+  long long act_stride;       // floats between consecutive layers in saved.act (= n_points_max * W)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -238,9 +240,19 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[NBO], const float* __rest
     }
 }
 
-// X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3])   (bias already inside acc, see init_acc)
+template <int NBO>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+}
+
+// X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3])   (bias already inside acc, see init_acc).
+// save (training): the same float4 also goes to row `save` of a row-major [N, 32*NBS] activation buffer
+// (this lane's point; the four q of one nb complete one 128-B line per row).
 template <int NBO, int NBS, bool RELU>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl) {
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, float* save = nullptr, int h = 0) {
 #pragma unroll
   for (int nb = 0; nb < NBS; ++nb)
 #pragma unroll
@@ -253,11 +265,32 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl) 
         v.w = fmaxf(v.w, 0.0f);
       }
       xl[(nb * 4 + q) * 64] = v;
+      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+    }
+}
+
+// dX-sweep epilogue: X[it][lane] = (x_in > 0) ? acc : 0 with x_in = the saved post-ReLU input of the layer
+// (row `xin` of a row-major activation buffer); optionally also stored to row `save` (backward pass).
+template <int NBO>
+__device__ __forceinline__ void store_masked(const f32x16 (&acc)[NBO], float4* xl, const float* __restrict__ xin, int h,
+                                             float* save = nullptr) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 x = *reinterpret_cast<const float4*>(xin + (nb * 4 + q) * 8 + 4 * h);
+      float4 v;
+      v.x = x.x > 0.0f ? acc[nb][4 * q + 0] : 0.0f;
+      v.y = x.y > 0.0f ? acc[nb][4 * q + 1] : 0.0f;
+      v.z = x.z > 0.0f ? acc[nb][4 * q + 2] : 0.0f;
+      v.w = x.w > 0.0f ? acc[nb][4 * q + 3] : 0.0f;
+      xl[(nb * 4 + q) * 64] = v;
+      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool TRAIN>
 __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
   constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;  // >= 13 (encoding) and >= 16 (mid hidden)
   constexpr int WAVE_F4 = (XITS + RSN_SH_ITS) * 64;
@@ -361,13 +394,18 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       }
       st3 = X[12 * 64];
     }
+    if (TRAIN && a.saved.enc && valid) {  // [N,104] in slot order
+      float* row = a.saved.enc + pc * RSN_K_ENC_PAD;
+#pragma unroll
+      for (int it = 0; it < RSN_ENC_ITS; ++it) *reinterpret_cast<float4*>(row + it * 8 + 4 * h) = X[it * 64];
+    }
 
     // ---------------- trunk -----------------
     {
       f32x16 acc[NB];
       init_acc<NB>(acc, pk + a.L.b[0], h);
       gemm<NB>(acc, pk + a.L.w_enc0, X, RSN_ENC_ITS, lane);
-      store_act<NB, NB, true>(acc, X);
+      store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + pc * W : nullptr, h);
 #pragma unroll 1
       for (int l = 1; l < a.num_layers; ++l) {
         init_acc<NB>(acc, pk + a.L.b[l], h);
@@ -382,7 +420,8 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           X[12 * 64] = st3;
           gemm<NB>(acc, pk + a.L.w_enc_skip, X, RSN_ENC_ITS, lane);
         }
-        store_act<NB, NB, true>(acc, X);  // ReLU between layers and out_activation=ReLU
+        // ReLU between layers and out_activation=ReLU
+        store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + l * a.act_stride + pc * W : nullptr, h);
       }
     }
     if (a.embedding && valid) {
@@ -429,8 +468,11 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           }
         }
       }
+      if (TRAIN && a.saved.heads && valid && h == 0) {  // raw normal head (3) + raw roughness head
+        *reinterpret_cast<float4*>(a.saved.heads + pc * 8) = make_float4(r1, r2, r3, r4);
+      }
       // bottleneck output (no activation) becomes the x-part of mlp_mid's input
-      store_act<NB + 1, NB, false>(acc, X);
+      store_act<NB + 1, NB, false>(acc, X, (TRAIN && a.saved.bott && valid) ? a.saved.bott + pc * W : nullptr, h);
     }
 
     // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
@@ -451,6 +493,9 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           vals[s] = (u < 17) ? (h ? sh[17 + u] : sh[u]) : 0.0f;
         }
         AUX[it * 64] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+        if (TRAIN && a.saved.sh && valid)
+          *reinterpret_cast<float4*>(a.saved.sh + pc * RSN_K_SH_PAD + it * 8 + 4 * h) =
+              make_float4(vals[0], vals[1], vals[2], vals[3]);
       }
     }
 
@@ -460,7 +505,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       init_acc<4>(accm, pk + a.L.b_mid, h);
       gemm<4>(accm, pk + a.L.w_mid_sh, AUX, RSN_SH_ITS, lane);
       gemm<4>(accm, pk + a.L.w_mid_x, X, NB * 4, lane);
-      store_act<4, 4, true>(accm, X);
+      store_act<4, 4, true>(accm, X, (TRAIN && a.saved.hid && valid) ? a.saved.hid + pc * 128 : nullptr, h);
     }
     {
       f32x16 accr[1];
@@ -470,6 +515,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         const float m0 = sigmoid_f(accr[0][0]);
         const float m1 = sigmoid_f(accr[0][1]);
         const float m2 = sigmoid_f(accr[0][2]);
+        if (TRAIN && a.saved.heads) *reinterpret_cast<float4*>(a.saved.heads + pc * 8 + 4) = make_float4(m0, m1, m2, 0.0f);
         if (a.out.color) {
           if (a.mode == RSN_MODE_INF) {
             a.out.color[pc * 3 + 0] = m0; a.out.color[pc * 3 + 1] = m1; a.out.color[pc * 3 + 2] = m2;
@@ -479,6 +525,66 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
             a.out.color[pc * 3 + 2] = dcol[2] + tcol[2] * m2;
           }
         }
+      }
+    }
+
+    // ---------------- training: analytic normals = -normalize(d raw_density / d contracted mean) -----------------
+    // (reflect_sampling_nerf_field.py:125-127,146-147 -> nerfstudio Field.get_normals).  A dX-only sweep back
+    // through the trunk: seed = density-head row masked by the embedding's ReLU, then W_l^T GEMMs masked by the
+    // saved activations; the encoded-input gradient accumulates in 4 extra blocks (slot order), and the chain
+    // through sin(2 pi x f [+ pi/2]) * exp(-var f^2 / 2) is closed per lane (the covariance is a constant here,
+    // exactly like the reference, which sets requires_grad on the mean after contraction).
+    if (TRAIN && a.saved.normals && a.saved.act) {
+      const float* __restrict__ wd = pk + a.L.v_density;
+      {
+        const float* embp = a.saved.act + (long long)(a.num_layers - 1) * a.act_stride + pc * W;
+#pragma unroll 4
+        for (int it = 0; it < NB * 4; ++it) {
+          const float4 e = *reinterpret_cast<const float4*>(embp + it * 8 + 4 * h);
+          const float4 w = *reinterpret_cast<const float4*>(wd + it * 8 + 4 * h);
+          X[it * 64] = make_float4(e.x > 0.0f ? w.x : 0.0f, e.y > 0.0f ? w.y : 0.0f, e.z > 0.0f ? w.z : 0.0f,
+                                   e.w > 0.0f ? w.w : 0.0f);
+        }
+      }
+      f32x16 eacc[4];
+      zero_acc<4>(eacc);
+#pragma unroll 1
+      for (int l = a.num_layers - 1; l >= 1; --l) {
+        if (l == a.skip_layer) gemm<4>(eacc, pk + a.L.wT_enc_skip, X, NB * 4, lane);
+        f32x16 acc[NB];
+        zero_acc<NB>(acc);
+        gemm<NB>(acc, pk + a.L.wT_x[l], X, NB * 4, lane);
+        store_masked<NB>(acc, X, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
+      }
+      gemm<4>(eacc, pk + a.L.wT_enc0, X, NB * 4, lane);
+      store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
+      float nrm[3];
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) {
+        const float x = (c == 0) ? mc[0] : (c == 1 ? mc[1] : mc[2]);
+        const float v = (c == 0) ? vc[0] : (c == 1 ? vc[1] : vc[2]);
+        const float sx = 6.283185307179586f * x;
+        float part = 0.0f;
+#pragma unroll 2
+        for (int jj = 0; jj < 8; ++jj) {
+          const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
+          const float ang = sx * f;
+          const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
+          const int u = c * 8 + jj;
+          const float gs = Xf[(u >> 2) * 256 + (u & 3)];
+          const float gc = Xf[((u + 24) >> 2) * 256 + ((u + 24) & 3)];
+          part += (gs * (e * cosf(ang)) + gc * (e * cosf(ang + 1.5707963267948966f))) * f;
+        }
+        part *= 6.283185307179586f;
+        if (h == 0) part += Xf[12 * 256 + c];  // the raw-coordinate input column
+        const float tot = part + __shfl_xor(part, 32, 64);
+        if (c == 0) nrm[0] = tot; else if (c == 1) nrm[1] = tot; else nrm[2] = tot;
+      }
+      if (h == 0 && valid) {
+        const float len = fmaxf(sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]), 1e-12f);
+        a.saved.normals[pc * 3 + 0] = -(nrm[0] / len);
+        a.saved.normals[pc * 3 + 1] = -(nrm[1] / len);
+        a.saved.normals[pc * 3 + 2] = -(nrm[2] / len);
       }
     }
   }
@@ -510,10 +616,21 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
   // one 4-wave workgroup per CU (one wave per SIMD, LDS slab 148 KiB at W=256): persistent tiles
   const long long grid = n_tiles < (long long)cus ? n_tiles : (long long)cus;
   hipStream_t st = (hipStream_t)stream;
+  const bool train = a.saved.act != nullptr || a.saved.enc != nullptr || a.saved.heads != nullptr;
+  a.act_stride = n_points * (long long)d->width;
   switch (d->width) {
-    case 256: hipLaunchKernelGGL(rsn_field_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
-    case 128: hipLaunchKernelGGL(rsn_field_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
-    case 64: hipLaunchKernelGGL(rsn_field_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    case 256:
+      if (train) hipLaunchKernelGGL((rsn_field_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((rsn_field_kernel<8, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      break;
+    case 128:
+      if (train) hipLaunchKernelGGL((rsn_field_kernel<4, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((rsn_field_kernel<4, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      break;
+    case 64:
+      if (train) hipLaunchKernelGGL((rsn_field_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((rsn_field_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      break;
     default: RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "width=%d unsupported", d->width);
   }
   RSN_HIP(hipGetLastError());
@@ -534,6 +651,27 @@ extern "C" int rsn_field_forward_frustum(const rsn_field_desc* desc, const float
   a.n_rays = n_rays; a.n_dev = n_dev; a.S = n_samples;
   a.origins = origins; a.directions = directions; a.pixel_area = pixel_area; a.bins = euclid_bins;
   a.out = *out;
+  return launch_field(desc, a, stream);
+}
+
+extern "C" int rsn_field_forward_frustum_train(const rsn_field_desc* desc, const float* packed, int32_t n_rays,
+                                               const int32_t* n_dev, int32_t n_samples, const float* origins,
+                                               const float* directions, const float* pixel_area,
+                                               const float* euclid_bins, const rsn_field_outputs* out,
+                                               const rsn_field_saved* saved, void* stream) {
+  RSN_REQUIRE(desc && out && saved, RSN_ERR_INVALID_ARGUMENT, "desc/out/saved is NULL");
+  RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
+  RSN_REQUIRE(n_rays == 0 || (origins && directions && pixel_area && euclid_bins), RSN_ERR_INVALID_ARGUMENT,
+              "a ray input pointer is NULL");
+  RSN_REQUIRE(saved->act && saved->enc && saved->bott && saved->sh && saved->hid && saved->heads,
+              RSN_ERR_INVALID_ARGUMENT, "training needs every saved-activation buffer (normals may be NULL)");
+  FieldArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_FRUSTUM;
+  a.n_rays = n_rays; a.n_dev = n_dev; a.S = n_samples;
+  a.origins = origins; a.directions = directions; a.pixel_area = pixel_area; a.bins = euclid_bins;
+  a.out = *out;
+  a.saved = *saved;
   return launch_field(desc, a, stream);
 }
 

@@ -73,6 +73,24 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   off += (size_t)(L->nbm * 4) * 1 * blk;
   L->b_rgb = off;
   off += 32;
+  // transposed segments
+  for (int l = 1; l < d->num_layers; ++l) {
+    L->wT_x[l] = off;
+    off += x_seg;
+  }
+  const size_t encT_seg = (size_t)(L->nb * 4) * 4 * blk;  // K = W, 4 row blocks (128 >= 104 slots)
+  L->wT_enc0 = off;
+  off += encT_seg;
+  L->wT_enc_skip = off;
+  off += (d->skip_layer >= 1) ? encT_seg : 0;
+  L->wT_bh = off;
+  off += (size_t)(L->nb * 4 + 4) * L->nb * blk;
+  L->wT_mid_x = off;
+  off += (size_t)(L->nbm * 4) * L->nb * blk;
+  L->wT_rgb = off;
+  off += (size_t)4 * L->nbm * blk;
+  L->v_density = off;
+  off += (size_t)d->width;
   L->total = off;
   return RSN_OK;
 }
@@ -92,7 +110,7 @@ struct PackJob {
   const float* src[PACK_MAX_SRC];
   int ld[PACK_MAX_SRC];
   float* dst;
-  int n_it, nbo, is_bias, n_rows;
+  int n_it, nbo, is_bias, n_rows, transpose;  // transpose: packed row n <- source COLUMN, packed k <- source ROW
   int16_t row_src[PACK_MAX_ROWS];  // which src a packed row comes from, -1 = zero row
   int16_t row_idx[PACK_MAX_ROWS];  // row inside that src
   int16_t col[PACK_MAX_COLS];      // source column of packed k, -1 = zero
@@ -119,7 +137,13 @@ __global__ void rsn_pack_kernel(const PackJob job) {
   const int rs = job.row_src[n];
   const int c = job.col[k];
   float v = 0.0f;
-  if (rs >= 0 && c >= 0) v = job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
+  if (job.transpose == 2) {  // overlay: write only live (row, k) pairs of a transposed source
+    if (rs >= 0 && c >= 0) job.dst[e] = job.src[rs][(size_t)c * job.ld[rs] + job.row_idx[n]];
+    return;
+  }
+  if (rs >= 0 && c >= 0)
+    v = job.transpose ? job.src[rs][(size_t)c * job.ld[rs] + job.row_idx[n]]
+                      : job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
   job.dst[e] = v;
 }
 
@@ -155,6 +179,17 @@ void cols_encoding(PackJob& j) {
     }
     j.col[k] = (int16_t)c;
   }
+}
+
+// the same slot order used as packed ROWS (transposed segments): packed row r <- reference column enc(r)
+int enc_slot_to_column(int k) {
+  const int it = k >> 3, h = (k >> 2) & 1, s = k & 3;
+  const int u = it * 4 + s;
+  if (k >= RSN_K_ENC_PAD) return -1;
+  if (u < 24) return (u / 8) * 16 + 8 * h + (u % 8);
+  if (u < 48) return 48 + ((u - 24) / 8) * 16 + 8 * h + ((u - 24) % 8);
+  if (u < 51 && h == 0) return 96 + (u - 48);
+  return -1;
 }
 
 // SH order: lane half h owns components 17h .. 17h+16 in slots 0..16 (slots 17..19 zero).
@@ -274,6 +309,70 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   clear_job(j);
   j.is_bias = 1; j.n_rows = 32; j.src[0] = p->rgb_b; j.dst = packed + L.b_rgb;
   for (int c = 0; c < 3; ++c) { j.row_src[4 + c] = 0; j.row_idx[4 + c] = (int16_t)c; }
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+
+  // ---------------- transposed segments (dX sweeps of the training path) ----------------
+  // With transpose=1 a packed ROW selects a source COLUMN (row_idx) and a packed k selects a source ROW (col).
+  for (int l = 1; l < d->num_layers; ++l) {
+    const int in_f = (l == d->skip_layer) ? RSN_ENC_DIM + W : W;
+    clear_job(j);
+    j.transpose = 1; j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; j.dst = packed + L.wT_x[l]; j.n_it = NB * 4; j.nbo = NB;
+    for (int n = 0; n < W; ++n) { j.row_src[n] = 0; j.row_idx[n] = (int16_t)((l == d->skip_layer ? RSN_ENC_DIM : 0) + n); }
+    cols_natural(j, W, 0);
+    if ((rc = launch(j, st)) != RSN_OK) return rc;
+  }
+  for (int which = 0; which < 2; ++which) {
+    const int l = which == 0 ? 0 : d->skip_layer;
+    if (l < 0) continue;
+    const int in_f = (l == 0) ? RSN_ENC_DIM : RSN_ENC_DIM + W;
+    clear_job(j);
+    j.transpose = 1; j.src[0] = p->trunk_w[l]; j.ld[0] = in_f;
+    j.dst = packed + (which == 0 ? L.wT_enc0 : L.wT_enc_skip); j.n_it = NB * 4; j.nbo = 4;
+    for (int n = 0; n < 128; ++n) {
+      const int c = enc_slot_to_column(n);
+      j.row_src[n] = (int16_t)(c >= 0 ? 0 : -1); j.row_idx[n] = (int16_t)(c >= 0 ? c : 0);
+    }
+    cols_natural(j, W, 0);
+    if ((rc = launch(j, st)) != RSN_OK) return rc;
+  }
+  {  // [bottleneck; heads]^T : rows = W input features; k < W -> bottleneck row k; k >= W -> heads row k - W
+    // one source per job row is not enough here (k selects the source), so pack the two K ranges separately
+    clear_job(j);
+    j.transpose = 1; j.src[0] = p->bottleneck_w; j.ld[0] = W; j.dst = packed + L.wT_bh; j.n_it = NB * 4; j.nbo = NB;
+    rows_natural(j, W); cols_natural(j, W, 0);
+    if ((rc = launch(j, st)) != RSN_OK) return rc;
+    // heads part: 4 K-iterations (k = 0..31 -> heads rows), one job per head tensor
+    const float* hw[5] = {p->density_w, p->normals_w, p->diff_w, p->roughness_w, p->tint_w};
+    const int hbase[5] = {0, 1, 4, 8, 12};
+    const int hrows[5] = {1, 3, 3, 1, 3};
+    // zero-fill then overlay: first a zero job
+    clear_job(j);
+    j.transpose = 1; j.src[0] = p->density_w; j.ld[0] = W; j.dst = packed + L.wT_bh + (size_t)(NB * 4) * NB * 256;
+    j.n_it = 4; j.nbo = NB;
+    rows_natural(j, W);  // all cols -1 -> zeros
+    if ((rc = launch(j, st)) != RSN_OK) return rc;
+    for (int t = 0; t < 5; ++t) {
+      clear_job(j);
+      j.transpose = 2;  // overlay: only write elements whose k is live
+      j.src[0] = hw[t]; j.ld[0] = W; j.dst = packed + L.wT_bh + (size_t)(NB * 4) * NB * 256; j.n_it = 4; j.nbo = NB;
+      rows_natural(j, W);
+      for (int c = 0; c < hrows[t]; ++c) j.col[hbase[t] + c] = (int16_t)c;
+      if ((rc = launch(j, st)) != RSN_OK) return rc;
+    }
+  }
+  clear_job(j);  // (mlp_mid bottleneck part)^T: rows = W (source columns 34..34+W), K = mid rows
+  j.transpose = 1; j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; j.dst = packed + L.wT_mid_x; j.n_it = NBM * 4; j.nbo = NB;
+  for (int n = 0; n < W; ++n) { j.row_src[n] = 0; j.row_idx[n] = (int16_t)(RSN_SH_DIM + n); }
+  cols_natural(j, d->mid_width, 0);
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+  clear_job(j);  // (RGB head)^T: rows = mid features, K = 32 with k = 4..6 -> rgb rows 0..2
+  j.transpose = 1; j.src[0] = p->rgb_w; j.ld[0] = d->mid_width; j.dst = packed + L.wT_rgb; j.n_it = 4; j.nbo = NBM;
+  rows_natural(j, d->mid_width);
+  for (int c = 0; c < 3; ++c) j.col[4 + c] = (int16_t)c;
+  if ((rc = launch(j, st)) != RSN_OK) return rc;
+  clear_job(j);
+  j.is_bias = 1; j.n_rows = W; j.src[0] = p->density_w; j.dst = packed + L.v_density;
+  rows_natural(j, W);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
   return RSN_OK;
 }

@@ -17,7 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _abi, ops
-from ._abi import FieldDesc, FieldParams, check, ptr
+from ._abi import FieldDesc, FieldParams, FieldSaved, check, ptr
 from .nerfstudio_compat import Field
 from .reflect_sampling_nerf_components import IntegratedSHEncoding, NeRFEncoding
 
@@ -185,6 +185,34 @@ class ReflectSamplingNeRFNerfField(Field):
         check(lib.rsn_field_forward_frustum(C.byref(desc), ptr(self.packed_weights()), R, ptr(n_dev), S, ptr(origins),
                                             ptr(directions), ptr(pixel_area), ptr(euclid_bins), C.byref(fo),
                                             ops._stream()))
+        return level
+
+    def evaluate_frustums_train(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid_bins: Tensor,
+                                n_dev: Optional[Tensor] = None, want_normals: bool = True) -> Dict[str, Tensor]:
+        """Training-mode level: same per-sample outputs as evaluate_frustums plus `raw_density`, the analytic
+        `normals` (Field.get_normals, when want_normals) and `saved` = the activations the backward pass needs."""
+        lib = _abi.load_library()
+        R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
+        N, W, L = R * S, self.width, self.mlp_base.num_layers
+        dev = origins.device
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        level = {"sigma": f(R, S), "color": f(R, S, 3), "pred_normals": f(R, S, 3), "n_dot_d": f(R, S),
+                 "diff": f(R, S, 3), "tint": f(R, S, 3), "roughness": f(R, S), "raw_density": f(R, S)}
+        saved = {"enc": f(N, 104), "act": f(L, N, W), "bott": f(N, W), "sh": f(N, 40), "hid": f(N, 128),
+                 "heads": f(N, 8)}
+        if want_normals:
+            saved["normals"] = f(R, S, 3)
+        fo = ops.field_outputs_struct(level)
+        fs = FieldSaved()
+        for k, v in saved.items():
+            setattr(fs, k, ptr(v))
+        desc = self.field_desc()
+        check(lib.rsn_field_forward_frustum_train(C.byref(desc), ptr(self.packed_weights()), R, ptr(n_dev), S,
+                                                  ptr(origins), ptr(directions), ptr(pixel_area), ptr(euclid_bins),
+                                                  C.byref(fo), C.byref(fs), ops._stream()))
+        level["saved"] = saved
+        if want_normals:
+            level["normals"] = saved["normals"]
         return level
 
     def evaluate_inf(self, directions: Tensor, sqradius: Tensor, n_dev: Optional[Tensor] = None) -> Tensor:

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     raw = C.CDLL(LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in rsn.h but not exported"
-    assert lib.rsn_abi_version() == 1
+    assert lib.rsn_abi_version() == _abi.RSN_ABI_VERSION
 
 
 def test_packed_size_and_argument_errors(lib):

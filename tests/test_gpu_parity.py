@@ -17,6 +17,10 @@ TOL = 1e-4
 # init), and the resampled fine positions (equal to the oracle's to ~1e-6) enter through IPE features whose
 # sensitivity reaches 2*pi*f*exp(-var f^2/2) ~ 3e3 per unit length.  Rendered quantities stay at TOL.
 TOL_UNIT = 5e-4
+# Analytic normals = normalised gradient of the raw density w.r.t. position: the gradient is dominated by the
+# highest undamped IPE frequencies (each term carries 2*pi*f), so ulp-level differences of the sample position are
+# amplified once more than for the predicted normals.  Bound: 2e-3 absolute on unit vectors (~0.1 degree).
+TOL_GRAD_NORMAL = 2e-3
 
 
 @pytest.fixture(scope="module")
@@ -289,3 +293,28 @@ def test_full_size_properties(dev):
                                   eb[:Rs].cpu(), training=False, want_normals=False)
     assert max_abs(lv["color"][:Rs].cpu(), ref["color"]) <= TOL
     assert max_abs(lv["sigma"][:Rs].cpu(), ref["sigma"][..., 0]) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------- training-mode forward
+@pytest.mark.parametrize("layers,width", [(8, 128), (4, 64), (8, 256)])
+def test_train_level_normals_and_saved_activations(dev, layers, width):
+    """Training-mode level: analytic normals (Field.get_normals: autograd of the raw density w.r.t. the contracted
+    mean) and the activations saved for the backward pass, against the oracle with the same jittered bins."""
+    R, S = 11, 20
+    fld, P, fs = make_field(layers, width, dev, seed=3 * layers + width, bias_shift=1.0)
+    fld.train()
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=8)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    g = torch.Generator().manual_seed(2)
+    _, eb = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S, torch.rand(R, S + 1, generator=g))
+    ref = cpu_ref.field_level(P, fs, o, d, pa, eb, training=True, want_normals=True)
+    lv = fld.evaluate_frustums_train(o.to(dev), d.to(dev), pa.reshape(R).to(dev), eb.contiguous().to(dev))
+    torch.cuda.synchronize()
+    assert max_abs(lv["sigma"].cpu(), ref["sigma"][..., 0].detach()) <= TOL
+    assert max_abs(lv["color"].cpu(), ref["color"].detach()) <= TOL
+    assert max_abs(lv["saved"]["act"][-1].cpu().reshape(R, S, width), ref["emb"].detach()) <= TOL
+    # analytic normals: unit vectors; compare where the raw gradient is not tiny (normalisation amplifies)
+    n_gpu, n_ref = lv["normals"].cpu(), ref["normals"].detach()
+    assert max_abs(n_gpu, n_ref) <= TOL_GRAD_NORMAL
+    assert float((n_gpu - n_ref).abs().mean()) <= 5e-5
+    assert float((n_gpu.norm(dim=-1) - 1).abs().max()) <= 1e-5
