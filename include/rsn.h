@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 2
+#define RSN_ABI_VERSION 3
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -147,6 +147,46 @@ int rsn_field_forward_frustum_train(const rsn_field_desc* desc, const float* pac
                                     const float* directions, const float* pixel_area, const float* euclid_bins,
                                     const rsn_field_outputs* out, const rsn_field_saved* saved, void* stream);
 
+/* ---- backward of one field level (training) ----------------------------------------------------
+ * Upstream gradients per sample (NULL = zero) ... */
+typedef struct rsn_field_grads_in {
+  const float* sigma;        /* [N]   d loss / d sigma (from rsn_composite_backward)                 */
+  const float* color;        /* [N,3] d loss / d colour                                              */
+  const float* pred_normals; /* [N,3] d loss / d pred_normals (predicted-normal loss, model.py:403-404) */
+  const float* n_dot_d;      /* [N]   d loss / d n_dot_d       (orientation loss, model.py:406-407)  */
+  const float* roughness;    /* [N]   d loss / d sigmoid(roughness head) (rendered roughness, model.py:225-226) */
+} rsn_field_grads_in;
+
+/* Pre-activation gradients of every linear layer, row-major, consumed by the weight-gradient GEMMs
+ * dW = dY^T X (plain library GEMMs on the host) and by rsn_colsum (bias gradients). */
+typedef struct rsn_field_grads_out {
+  float* dz_rgb;    /* [N,4]   field_output_mid pre-sigmoid (3 live columns)                          */
+  float* da_mid;    /* [N,128] mlp_mid pre-activation                                                  */
+  float* d_bott;    /* [N,W]   bottleneck output                                                       */
+  float* dz_heads;  /* [N,16]  columns: 0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint      */
+  float* dy;        /* [L,N,W] pre-activation of trunk layer l                                         */
+  float* d_input;   /* [N]     d loss / d pixel_area (frustum) or d sqradius (inf); need_input_grad only */
+} rsn_field_grads_out;
+
+/* rsn_field_backward_frustum: backward of rsn_field_forward_frustum_train.  fwd: the forward's per-sample
+ * outputs (raw_density, diff, tint are read).  need_input_grad != 0 additionally carries the gradient through
+ * the integrated positional encoding's variance back to pixel_area (reflected rays: pixel_area = pi*sqradius
+ * depends on the non-detached rendered roughness, reflect_sampling_nerf_model.py:225-227,272,286). */
+int rsn_field_backward_frustum(const rsn_field_desc* desc, const float* packed, int32_t n_rays, const int32_t* n_dev,
+                               int32_t n_samples, const float* origins, const float* directions,
+                               const float* pixel_area, const float* euclid_bins, const rsn_field_outputs* fwd,
+                               const rsn_field_saved* saved, const rsn_field_grads_in* gin,
+                               const rsn_field_grads_out* gout, int32_t need_input_grad, void* stream);
+
+/* Training variant / backward of rsn_field_forward_inf (get_inf_color, field.py:190-201). */
+int rsn_field_forward_inf_train(const rsn_field_desc* desc, const float* packed, int32_t n_rays, const int32_t* n_dev,
+                                const float* directions, const float* sqradius, float* out_rgb,
+                                const rsn_field_saved* saved, void* stream);
+int rsn_field_backward_inf(const rsn_field_desc* desc, const float* packed, int32_t n_rays, const int32_t* n_dev,
+                           const float* directions, const float* sqradius, const rsn_field_saved* saved,
+                           const float* g_rgb, const rsn_field_grads_out* gout, int32_t need_input_grad,
+                           void* stream);
+
 /* rsn_field_forward_inf: get_inf_color (reflect_sampling_nerf_field.py:190-201): mean = 2d,
  * Sigma = 0.6*sqradius*(I - d d^T), no contraction, SH inputs zeroed; out_rgb [M,3]. */
 int rsn_field_forward_inf(const rsn_field_desc* desc, const float* packed, int32_t n_rays, const int32_t* n_dev,
@@ -196,6 +236,51 @@ typedef struct rsn_composite_io {
 int rsn_composite(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t background, int32_t flags,
                   const rsn_composite_io* io, void* stream);
 
+/* rsn_composite_backward: backward of rsn_composite in training mode (no eval clamp).
+ * g_rgb [R,3]: gradient w.r.t. the rgb output (after the model's clip when RSN_COMP_CLIP_RGB: masked where the
+ * unclipped composite left [0,1]); g_roughness [R] (or NULL): gradient w.r.t. the rendered roughness;
+ * weights: the forward's weights [R,S].  detach_weights != 0: the weights were detached (reflect levels,
+ * model.py:297,323): no gradient reaches sigma.  Outputs (NULL = skip): g_sigma [R,S], g_color [R,S,3],
+ * g_roughness_sample [R,S], g_bg [R,3] (background == 2). */
+typedef struct rsn_composite_bwd_io {
+  const float* sigma;
+  const float* euclid_bins;
+  const float* color;
+  const float* bg_rgb;
+  const float* roughness;       /* [R,S] per-sample sigmoid roughness (or NULL) */
+  const float* weights;
+  const float* g_rgb;
+  const float* g_roughness;
+  const float* g_accumulation;  /* [R] or NULL: gradient w.r.t. sum_s w (model.py:240-241: white*(1-acc_fine)) */
+  float* g_sigma;
+  float* g_color;
+  float* g_roughness_sample;
+  float* g_bg;
+} rsn_composite_bwd_io;
+
+int rsn_composite_backward(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t background, int32_t flags,
+                           int32_t detach_weights, const rsn_composite_bwd_io* io, void* stream);
+
+/* rsn_colsum: out[c] (+)= sum_r x[r*ld + c], c < n_cols (bias gradients = column sums of dY). */
+int rsn_colsum(int64_t n_rows, int32_t n_cols, int32_t ld, const float* x, float* out, int32_t accumulate,
+               void* stream);
+
+/* rsn_ray_sum: out[r] = sum_s x[r*S + s]  (per-ray total of a per-sample quantity). */
+int rsn_ray_sum(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, const float* x, float* out, void* stream);
+
+/* rsn_reflect_backward: gradient of the secondary-ray construction w.r.t. the rendered roughness
+ * (reflect_sampling_nerf_model.py:272,286): sqradius = 2|n.d| roughness^2, pixel_area = pi * sqradius.
+ * g_roughness[ray_index[i]] = (g_sqradius[i] + pi * g_pixel_area[i]) * 2|n.d| * 2 roughness, zero elsewhere. */
+int rsn_reflect_backward(int32_t n_rays, const int32_t* n_masked, const int32_t* ray_index, const float* n_dot_d,
+                         const float* roughness, const float* g_sqradius, const float* g_pixel_area,
+                         float* g_roughness, void* stream);
+
+/* rsn_reflect_default_backward: rays that are NOT reflected keep mid_reflect_{coarse,fine} = white*(1-acc_fine)
+ * with a live accumulation (reflect_sampling_nerf_model.py:240-241):
+ * g_accumulation[r] = mask[r] ? 0 : -sum_c (g_reflect_coarse[r,c] + g_reflect_fine[r,c]). */
+int rsn_reflect_default_backward(int32_t n_rays, const uint8_t* mask, const float* g_reflect_coarse,
+                                 const float* g_reflect_fine, float* g_accumulation, void* stream);
+
 /* ---- reflection rays --------------------------------------------------------------------------
  * rsn_reflect_setup: reflect_sampling_nerf_model.py:222-229,240-241,267-289: n_dot_d, mask =
  * (acc > 1e-2) & (n_dot_d < 0), stable compaction of the masked rays, secondary-ray origins /
@@ -230,6 +315,12 @@ int rsn_reflect_setup(int32_t n_rays, float reflect_far, const rsn_reflect_io* i
  * for i < *n_masked (reflect_sampling_nerf_model.py:312-313,338-339). */
 int rsn_reflect_combine(int32_t n_rays_max, const int32_t* n_masked, const int32_t* ray_index, const float* diff,
                         const float* tint, const float* comp, float* out, void* stream);
+
+/* rsn_reflect_combine_backward: backward of rsn_reflect_combine w.r.t. the composite (diff/tint are detached,
+ * reflect_sampling_nerf_model.py:216,218): g_comp[i] = g_out[r] * tint[r] where 0 <= diff[r]+tint[r]*comp[i] <= 1. */
+int rsn_reflect_combine_backward(int32_t n_rays_max, const int32_t* n_masked, const int32_t* ray_index,
+                                 const float* diff, const float* tint, const float* comp, const float* g_out,
+                                 float* g_comp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -457,6 +457,11 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     white = torch.ones(3)
     jit = (lambda k: jitter[k]) if training else (lambda k: None)
 
+    def jit_reflect(k, mask):
+        """reflect-level jitter may be given per original ray [R,S+1]; the masked rows are used then."""
+        t = jit(k)
+        return t[mask] if (t is not None and t.shape[0] == mask.shape[0] and t.shape[0] != int(mask.sum())) else t
+
     # A. coarse primary (model.py:148-177)
     sbins_c, ebins_c = spaced_bins("uniform", 1.0, nears, fars, ms.num_coarse, jit("coarse"))
     lc = field_level(P, fs, origins, directions, pixel_area, ebins_c, training, want_normals=True)
@@ -519,7 +524,7 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
 
     # F. reflect coarse (model.py:292-313)
     sb_rc, eb_rc = spaced_bins("reciprocal", ms.reflect_tan, near2, far2, ms.num_reflect_coarse,
-                               jit("reflect_coarse"))
+                               jit_reflect("reflect_coarse", mask))
     lrc = field_level(P, fs, o2, d2, pa2, eb_rc, training, want_normals=False)
     w_rc = weights_from_density(lrc["sigma"], lrc["t0"], lrc["t1"]).detach()
     comp_rc = composite_rgb(lrc["color"], w_rc, background, training)
@@ -529,7 +534,7 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
 
     # G. reflect fine (model.py:317-342)
     sb_rf, eb_rf = pdf_bins("reciprocal", ms.reflect_tan, near2, far2, w_rc, sb_rc, ms.num_reflect_fine,
-                            jit("reflect_fine"), ms.histogram_padding)
+                            jit_reflect("reflect_fine", mask), ms.histogram_padding)
     lrf = field_level(P, fs, o2, d2, pa2, eb_rf, training, want_normals=False)
     w_rf = weights_from_density(lrf["sigma"], lrf["t0"], lrf["t1"]).detach()
     comp_rf = composite_rgb(lrf["color"], w_rf, background, training)

@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 2
+RSN_ABI_VERSION = 3
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -53,6 +53,20 @@ class FieldSaved(C.Structure):
     _fields_ = [(n, _fp) for n in ("enc", "act", "bott", "sh", "hid", "heads", "normals")]
 
 
+class FieldGradsIn(C.Structure):
+    _fields_ = [(n, _fp) for n in ("sigma", "color", "pred_normals", "n_dot_d", "roughness")]
+
+
+class FieldGradsOut(C.Structure):
+    _fields_ = [(n, _fp) for n in ("dz_rgb", "da_mid", "d_bott", "dz_heads", "dy", "d_input")]
+
+
+class CompositeBwdIO(C.Structure):
+    _fields_ = [(n, _fp) for n in ("sigma", "euclid_bins", "color", "bg_rgb", "roughness", "weights", "g_rgb",
+                                   "g_roughness", "g_accumulation", "g_sigma", "g_color", "g_roughness_sample",
+                                   "g_bg")]
+
+
 class CompositeIO(C.Structure):
     _fields_ = [(n, _fp) for n in
                 ("sigma", "euclid_bins", "color", "bg_rgb", "diff", "tint", "pred_normals", "roughness",
@@ -80,6 +94,21 @@ _SIGNATURES = {
     "rsn_field_forward_frustum_train": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, C.c_int32, _fp, _fp,
                                                   _fp, _fp, C.POINTER(FieldOutputs), C.POINTER(FieldSaved),
                                                   C.c_void_p]),
+    "rsn_field_backward_frustum": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, _fp,
+                                             C.POINTER(FieldOutputs), C.POINTER(FieldSaved),
+                                             C.POINTER(FieldGradsIn), C.POINTER(FieldGradsOut), C.c_int32,
+                                             C.c_void_p]),
+    "rsn_field_forward_inf_train": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp, _fp,
+                                              C.POINTER(FieldSaved), C.c_void_p]),
+    "rsn_field_backward_inf": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp, C.POINTER(FieldSaved),
+                                         _fp, C.POINTER(FieldGradsOut), C.c_int32, C.c_void_p]),
+    "rsn_composite_backward": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.POINTER(CompositeBwdIO), C.c_void_p]),
+    "rsn_colsum": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, C.c_void_p]),
+    "rsn_ray_sum": (C.c_int, [C.c_int32, _fp, C.c_int32, _fp, _fp, C.c_void_p]),
+    "rsn_reflect_backward": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_reflect_default_backward": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_reflect_combine_backward": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_field_forward_inf": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_field_forward_gaussians": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp,
                                               C.POINTER(FieldOutputs), _fp, C.c_void_p]),

@@ -1,0 +1,361 @@
+// rsn_field_bwd.hip -- backward sweep of the field for one sampling level (training).
+//
+// Mirror image of rsn_field.hip: one wavefront owns 32 sample points and walks the network backwards with the
+// TRANSPOSED packed weights (rsn_pack.hip, wT_* segments).  dX[k][m] = sum_n W[n][k] * dY[n][m] has the same
+// "A = weights, B = points" shape as the forward GEMM, so the lane-local trick carries over unchanged: the
+// accumulator registers a lane holds after one W^T GEMM are (after the ReLU mask) the B operand it needs for the
+// next one.  ReLU masks come from the post-ReLU activations the training forward saved (x > 0).
+//
+// What leaves the kernel are the PRE-ACTIVATION gradients of every linear layer, row-major [N, out_features]:
+// the weight gradients dW = dY^T X (contraction over all N samples) are plain, large GEMMs and are taken by the
+// host with the BLAS library (hipBLASLt/rocBLAS through torch.mm), the bias gradients by rsn_colsum.
+//
+// Autograd semantics restated (reference: reflect_sampling_nerf_model.py:142-344, field.py:122-207):
+//   colour = diff + tint * mid          -> d diff = g, d tint = g*mid, d mid = g*tint
+//   SH inputs carry no gradient (components.py:52, roughness.detach() at model.py:174)
+//   pred_normals = normalize(-normalize(head))      n_dot_d = sum(dir * pred_normals)
+//   sigma = softplus(raw + density_bias)            roughness (rendered) = sum w * sigmoid(raw)
+//   reflect levels: the Gaussian covariance depends on pixel_area = pi * sqradius (a function of the NON-detached
+//   rendered roughness, model.py:225-227,272,286), so the gradient w.r.t. the encoded inputs' variance is carried
+//   back to pixel_area (need_input_grad).
+#include "rsn_mfma.h"
+
+struct BwdArgs {
+  const float* packed;
+  RsnPackedLayout L;
+  int num_layers, skip_layer;
+  float density_bias;
+  float freqs[RSN_NUM_FREQS];
+  int mode, n_rays, S, need_input_grad;
+  const int* n_dev;
+  const float* origins;
+  const float* directions;
+  const float* pixel_area;
+  const float* bins;
+  const float* sqradius;
+  rsn_field_grads_in gin;
+  rsn_field_outputs fwd;   // forward per-sample values: raw_density, diff, tint
+  rsn_field_saved saved;
+  rsn_field_grads_out gout;
+  long long act_stride;
+};
+
+// d var_c / d pixel_area for a conical-frustum sample after contraction (the mean does not depend on pixel_area):
+// var_c = relu(diag(J Sigma J))_c, Sigma = var_t d d^T + var_r (I - d (d/|d|^2)^T), var_r = (pa / 1.7724538509^2) Kr(t).
+__device__ __forceinline__ void frustum_dvar_dpa(const float o[3], const float d[3], float pa, float t0, float t1,
+                                                 float out[3]) {
+  const float radius = sqrtf(pa) / 1.7724538509055159f;
+  const float mu = (t0 + t1) / 2.0f;
+  const float hw = (t1 - t0) / 2.0f;
+  const float hw2 = hw * hw, mu2 = mu * mu;
+  const float den = 3.0f * mu2 + hw2;
+  const float tmean = mu + (2.0f * mu * hw2) / den;
+  float mean[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) mean[c] = o[c] + d[c] * tmean;
+  const float hw4 = hw2 * hw2;
+  const float var_t = hw2 / 3.0f - 0.26666666666666666f * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+  const float kr = mu2 / 4.0f + 0.4166666666666667f * hw2 - (0.26666666666666666f * hw4) / den;
+  const float var_r = (radius * radius) * kr;
+  const float dmag = fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f);
+  float S[3][3], Nn[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Nn[i][j] = (i == j ? 1.0f : 0.0f) - d[i] * (d[j] / dmag);
+      S[i][j] = var_t * (d[i] * d[j]) + var_r * Nn[i][j];
+    }
+  const float n2 = mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2];
+  const float n = sqrtf(n2);
+  float J[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float eye = (i == j) ? 1.0f : 0.0f;
+      J[i][j] = (n > 1.0f) ? ((2.0f * n - 2.0f) * (eye - mean[i] * mean[j] / n2) + eye) / n2 : eye;
+    }
+  // d(radius^2)/d(pa) = 1 / 1.7724538509^2
+  const float dr2 = kr / (1.7724538509055159f * 1.7724538509055159f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float vs = 0.0f, vn = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float js = J[i][0] * S[0][b] + J[i][1] * S[1][b] + J[i][2] * S[2][b];
+      const float jn = J[i][0] * Nn[0][b] + J[i][1] * Nn[1][b] + J[i][2] * Nn[2][b];
+      vs += js * J[b][i];
+      vn += jn * J[b][i];
+    }
+    out[i] = vs > 0.0f ? vn * dr2 : 0.0f;  // relu on the diagonal (reflect_sampling_nerf_field.py:114-115)
+  }
+}
+
+// F.normalize backward: y = x / max(|x|, eps);  g_x = (g_y - y (y . g_y)) / |x|
+__device__ __forceinline__ void normalize_bwd(const float x[3], const float gy[3], float gx[3]) {
+  const float len = fmaxf(sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]), 1e-12f);
+  const float y0 = x[0] / len, y1 = x[1] / len, y2 = x[2] / len;
+  const float dot = y0 * gy[0] + y1 * gy[1] + y2 * gy[2];
+  gx[0] = (gy[0] - y0 * dot) / len;
+  gx[1] = (gy[1] - y1 * dot) / len;
+  gx[2] = (gy[2] - y2 * dot) / len;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
+  constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;
+  constexpr int WAVE_F4 = (XITS + RSN_SH_ITS) * 64;
+  constexpr int W = NB * 32;
+  __shared__ float4 smem[4 * WAVE_F4];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  float4* X = smem + wid * WAVE_F4 + lane;  // its XITS.. spill into the SH region (contiguous): NB*4+4 <= XITS+5
+  float* Xf = reinterpret_cast<float*>(X);
+
+  int n_rays = a.n_rays;
+  if (a.n_dev) {
+    const int nd = *a.n_dev;
+    n_rays = nd < n_rays ? nd : n_rays;
+  }
+  const long long n_points = (long long)n_rays * a.S;
+  const long long n_tiles = (n_points + 127) / 128;
+  const float* __restrict__ pk = a.packed;
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long p0 = tile * 128 + wid * 32;
+    if (p0 >= n_points) continue;
+    const long long p = p0 + m;
+    const bool valid = p < n_points;
+    const long long pc = valid ? p : n_points - 1;
+    const float live = valid ? 1.0f : 0.0f;  // padded lanes contribute zero gradients
+
+    // ---------------- per-sample epilogue gradients -----------------
+    float gcol[3] = {0.0f, 0.0f, 0.0f};
+    if (a.gin.color) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gcol[c] = a.gin.color[pc * 3 + c] * live;
+    }
+    const float4 hd = *reinterpret_cast<const float4*>(a.saved.heads + pc * 8);       // n_raw(3), rough_raw
+    const float4 md = *reinterpret_cast<const float4*>(a.saved.heads + pc * 8 + 4);   // mid RGB (3)
+    float mid[3] = {md.x, md.y, md.z};
+    float dif[3] = {0.0f, 0.0f, 0.0f}, tin[3] = {1.0f, 1.0f, 1.0f};
+    if (a.mode != RSN_MODE_INF) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dif[c] = a.fwd.diff[pc * 3 + c];
+        tin[c] = a.fwd.tint[pc * 3 + c];
+      }
+    }
+    // RGB head: colour = diff + tint * mid (INF: colour = mid); mid = sigmoid(z)
+    float dz_rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dz_rgb[c] = gcol[c] * tin[c] * (mid[c] * (1.0f - mid[c]));
+    if (h == 1 && valid && a.gout.dz_rgb)
+      *reinterpret_cast<float4*>(a.gout.dz_rgb + pc * 4) = make_float4(dz_rgb[0], dz_rgb[1], dz_rgb[2], 0.0f);
+
+    // ---------------- stage 1: d hidden = W_rgb^T dz  (K = 32 with rows 4..6 live), ReLU mask -----------------
+    X[0] = (h == 1) ? make_float4(dz_rgb[0], dz_rgb[1], dz_rgb[2], 0.0f) : zero4;
+    X[64] = zero4; X[128] = zero4; X[192] = zero4;
+    {
+      f32x16 acc[4];
+      zero_acc<4>(acc);
+      gemm<4>(acc, pk + a.L.wT_rgb, X, 4, lane);
+      store_masked<4>(acc, X, a.saved.hid + pc * 128, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
+    }
+    // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
+    {
+      f32x16 acc[NB];
+      zero_acc<NB>(acc);
+      gemm<NB>(acc, pk + a.L.wT_mid_x, X, 16, lane);
+      store_act<NB, NB, false>(acc, X, (valid && a.gout.d_bott) ? a.gout.d_bott + pc * W : nullptr, h);
+    }
+    // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
+    {
+      float4 q0 = zero4, q1 = zero4;  // heads rows 8q + 4h + j for q = 0, 1
+      if (a.mode != RSN_MODE_INF) {
+        if (h == 0) {
+          const float raw = a.fwd.raw_density[pc];
+          const float gs = a.gin.sigma ? a.gin.sigma[pc] * live : 0.0f;
+          q0.x = gs * sigmoid_f(raw + a.density_bias);  // softplus'
+          // predicted normal: pn = normalize(-normalize(n_raw)); G = g_pn + g_ndd * dir
+          float dir[3], G[3] = {0.0f, 0.0f, 0.0f};
+          const long long ray = pc / a.S;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) dir[c] = a.directions[ray * 3 + c];
+          if (a.gin.pred_normals) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G[c] = a.gin.pred_normals[pc * 3 + c] * live;
+          }
+          if (a.gin.n_dot_d) {
+            const float gd = a.gin.n_dot_d[pc] * live;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G[c] += gd * dir[c];
+          }
+          const float nraw[3] = {hd.x, hd.y, hd.z};
+          const float len = fmaxf(sqrtf(nraw[0] * nraw[0] + nraw[1] * nraw[1] + nraw[2] * nraw[2]), 1e-12f);
+          const float v[3] = {-(nraw[0] / len), -(nraw[1] / len), -(nraw[2] / len)};
+          float gv[3], gu[3], gn[3];
+          normalize_bwd(v, G, gv);
+          gu[0] = -gv[0]; gu[1] = -gv[1]; gu[2] = -gv[2];
+          normalize_bwd(nraw, gu, gn);
+          q0.y = gn[0]; q0.z = gn[1]; q0.w = gn[2];
+          const float sr = sigmoid_f(hd.w);
+          const float gr = a.gin.roughness ? a.gin.roughness[pc] * live : 0.0f;
+          q1.x = gr * sr * (1.0f - sr);
+        } else {
+          q0.x = gcol[0] * (dif[0] * (1.0f - dif[0]));
+          q0.y = gcol[1] * (dif[1] * (1.0f - dif[1]));
+          q0.z = gcol[2] * (dif[2] * (1.0f - dif[2]));
+          q1.x = gcol[0] * mid[0] * (tin[0] * (1.0f - tin[0]));
+          q1.y = gcol[1] * mid[1] * (tin[1] * (1.0f - tin[1]));
+          q1.z = gcol[2] * mid[2] * (tin[2] * (1.0f - tin[2]));
+        }
+      }
+      X[(NB * 4 + 0) * 64] = q0;
+      X[(NB * 4 + 1) * 64] = q1;
+      X[(NB * 4 + 2) * 64] = zero4;
+      X[(NB * 4 + 3) * 64] = zero4;
+      if (valid && a.gout.dz_heads) {
+        *reinterpret_cast<float4*>(a.gout.dz_heads + pc * 16 + 4 * h) = q0;
+        *reinterpret_cast<float4*>(a.gout.dz_heads + pc * 16 + 8 + 4 * h) = q1;
+      }
+      f32x16 acc[NB];
+      zero_acc<NB>(acc);
+      gemm<NB>(acc, pk + a.L.wT_bh, X, NB * 4 + 4, lane);
+      const int l = a.num_layers - 1;
+      store_masked<NB>(acc, X, a.saved.act + (long long)l * a.act_stride + pc * W, h,
+                       valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
+    }
+    // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
+    f32x16 eacc[4];
+    zero_acc<4>(eacc);
+#pragma unroll 1
+    for (int l = a.num_layers - 1; l >= 1; --l) {
+      if (a.need_input_grad && l == a.skip_layer) gemm<4>(eacc, pk + a.L.wT_enc_skip, X, NB * 4, lane);
+      f32x16 acc[NB];
+      zero_acc<NB>(acc);
+      gemm<NB>(acc, pk + a.L.wT_x[l], X, NB * 4, lane);
+      store_masked<NB>(acc, X, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h,
+                       valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
+    }
+    // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
+    if (a.need_input_grad) {
+      gemm<4>(eacc, pk + a.L.wT_enc0, X, NB * 4, lane);
+      store_act<4, 4, false>(eacc, X);  // d loss / d encoded input, slot order
+      const float* encp = a.saved.enc + pc * RSN_K_ENC_PAD;
+      float dvar[3];
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) {
+        float part = 0.0f;
+#pragma unroll 2
+        for (int jj = 0; jj < 8; ++jj) {
+          const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
+          const int u = c * 8 + jj, u2 = u + 24;
+          const float gs = Xf[(u >> 2) * 256 + (u & 3)], gc = Xf[(u2 >> 2) * 256 + (u2 & 3)];
+          const float fs = encp[(u >> 2) * 8 + 4 * h + (u & 3)], fc = encp[(u2 >> 2) * 8 + 4 * h + (u2 & 3)];
+          part += (-0.5f * (f * f)) * (gs * fs + gc * fc);  // d/dvar [exp(-var f^2/2) sin(.)] = -f^2/2 * feature
+        }
+        const float tot = part + __shfl_xor(part, 32, 64);
+        if (c == 0) dvar[0] = tot; else if (c == 1) dvar[1] = tot; else dvar[2] = tot;
+      }
+      if (h == 0 && valid && a.gout.d_input) {
+        float g = 0.0f;
+        if (a.mode == RSN_MODE_FRUSTUM) {
+          const long long ray = pc / a.S;
+          const int s = (int)(pc - ray * a.S);
+          float o[3], d[3], dv[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { o[c] = a.origins[ray * 3 + c]; d[c] = a.directions[ray * 3 + c]; }
+          frustum_dvar_dpa(o, d, a.pixel_area[ray], a.bins[ray * (a.S + 1) + s], a.bins[ray * (a.S + 1) + s + 1], dv);
+          g = dvar[0] * dv[0] + dvar[1] * dv[1] + dvar[2] * dv[2];
+        } else {  // INF: var_c = (0.6 sq)(1 - d_c^2)   (reflect_sampling_nerf_field.py:196)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float dc = a.directions[pc * 3 + c];
+            g += dvar[c] * (0.6f * (1.0f - dc * dc));
+          }
+        }
+        a.gout.d_input[pc] = g;
+      }
+    }
+  }
+}
+
+static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
+  int rc = rsn_compute_layout(d, &a.L);
+  if (rc != RSN_OK) return rc;
+  RSN_REQUIRE(a.packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "packed weights pointer is NULL");
+  RSN_REQUIRE(a.saved.act && a.saved.hid && a.saved.heads && a.gout.dy, RSN_ERR_INVALID_ARGUMENT,
+              "saved activations (act, hid, heads) and gout.dy are required");
+  RSN_REQUIRE(!a.need_input_grad || (a.saved.enc && a.gout.d_input), RSN_ERR_INVALID_ARGUMENT,
+              "need_input_grad needs saved.enc and gout.d_input");
+  RSN_REQUIRE(a.mode == RSN_MODE_INF || (a.fwd.raw_density && a.fwd.diff && a.fwd.tint), RSN_ERR_INVALID_ARGUMENT,
+              "forward values raw_density/diff/tint are required");
+  a.num_layers = d->num_layers;
+  a.skip_layer = d->skip_layer;
+  a.density_bias = d->density_bias;
+  for (int i = 0; i < RSN_NUM_FREQS; ++i) a.freqs[i] = d->freqs[i];
+  if (a.n_rays <= 0) return RSN_OK;
+  const long long n_points = (long long)a.n_rays * a.S;
+  a.act_stride = n_points * (long long)d->width;
+  const long long n_tiles = (n_points + 127) / 128;
+  static int cached_cus = 0;
+  if (cached_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cached_cus = n;
+    else
+      cached_cus = 256;
+  }
+  const long long grid = n_tiles < (long long)cached_cus ? n_tiles : (long long)cached_cus;
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->width) {
+    case 256: hipLaunchKernelGGL(rsn_field_bwd_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    case 128: hipLaunchKernelGGL(rsn_field_bwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL(rsn_field_bwd_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    default: RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "width=%d unsupported", d->width);
+  }
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+extern "C" int rsn_field_backward_frustum(const rsn_field_desc* desc, const float* packed, int32_t n_rays,
+                                          const int32_t* n_dev, int32_t n_samples, const float* origins,
+                                          const float* directions, const float* pixel_area, const float* euclid_bins,
+                                          const rsn_field_outputs* fwd, const rsn_field_saved* saved,
+                                          const rsn_field_grads_in* gin, const rsn_field_grads_out* gout,
+                                          int32_t need_input_grad, void* stream) {
+  RSN_REQUIRE(desc && fwd && saved && gin && gout, RSN_ERR_INVALID_ARGUMENT, "a struct pointer is NULL");
+  RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
+  RSN_REQUIRE(n_rays == 0 || (origins && directions && pixel_area && euclid_bins), RSN_ERR_INVALID_ARGUMENT,
+              "a ray input pointer is NULL");
+  BwdArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_FRUSTUM;
+  a.n_rays = n_rays; a.n_dev = n_dev; a.S = n_samples; a.need_input_grad = need_input_grad;
+  a.origins = origins; a.directions = directions; a.pixel_area = pixel_area; a.bins = euclid_bins;
+  a.gin = *gin; a.fwd = *fwd; a.saved = *saved; a.gout = *gout;
+  return launch_bwd(desc, a, stream);
+}
+
+extern "C" int rsn_field_backward_inf(const rsn_field_desc* desc, const float* packed, int32_t n_rays,
+                                      const int32_t* n_dev, const float* directions, const float* sqradius,
+                                      const rsn_field_saved* saved, const float* g_rgb,
+                                      const rsn_field_grads_out* gout, int32_t need_input_grad, void* stream) {
+  RSN_REQUIRE(desc && saved && gout, RSN_ERR_INVALID_ARGUMENT, "a struct pointer is NULL");
+  RSN_REQUIRE(n_rays >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
+  RSN_REQUIRE(n_rays == 0 || (directions && sqradius && g_rgb), RSN_ERR_INVALID_ARGUMENT, "an input pointer is NULL");
+  BwdArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_INF;
+  a.n_rays = n_rays; a.n_dev = n_dev; a.S = 1; a.need_input_grad = need_input_grad;
+  a.directions = directions; a.sqradius = sqradius;
+  a.gin.color = g_rgb;
+  a.saved = *saved; a.gout = *gout;
+  return launch_bwd(desc, a, stream);
+}

@@ -320,6 +320,203 @@ extern "C" int rsn_composite(int32_t n_rays, const int32_t* n_dev, int32_t n_sam
 }
 
 // ---------------------------------------------------------------------------------------------------
+// compositing backward (training).  w_i = (1 - e^{-x_i}) T_i, x_i = delta_i sigma_i, T_i = exp(-sum_{j<i} x_j):
+//   dL/dx_k = g_w[k] * T_{k+1} - sum_{i>k} g_w[i] w_i          (T_{k+1} = T_k - w_k)
+// One wave per ray; the suffix sum is total - inclusive prefix, both in fp64.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rsn_composite_bwd_kernel(int n_rays, const int* n_dev, int S, int background,
+                                                                int flags, int detach_weights,
+                                                                const rsn_composite_bwd_io io) {
+  const int R = dyn_count(n_rays, n_dev);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int ray = blockIdx.x * 4 + wid; ray < R; ray += gridDim.x * 4) {
+    const long long sbase = (long long)ray * S;
+    const float* bins = io.euclid_bins + (long long)ray * (S + 1);
+    float bg[3] = {0.0f, 0.0f, 0.0f};
+    if (background == 1) bg[0] = bg[1] = bg[2] = 1.0f;
+    if (background == 2) { bg[0] = io.bg_rgb[ray * 3 + 0]; bg[1] = io.bg_rgb[ray * 3 + 1]; bg[2] = io.bg_rgb[ray * 3 + 2]; }
+    // pass 1: unclipped composite and accumulation (clip mask of the model's torch.clip)
+    float acc = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    for (int i = lane; i < S; i += 64) {
+      const float w = io.weights[sbase + i];
+      acc += w;
+      c0 += w * io.color[(sbase + i) * 3 + 0];
+      c1 += w * io.color[(sbase + i) * 3 + 1];
+      c2 += w * io.color[(sbase + i) * 3 + 2];
+    }
+    acc = wave_sum(acc); c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+    const float rem = 1.0f - acc;
+    if (background != 0) { c0 = c0 + bg[0] * rem; c1 = c1 + bg[1] * rem; c2 = c2 + bg[2] * rem; }
+    float g[3] = {io.g_rgb[ray * 3 + 0], io.g_rgb[ray * 3 + 1], io.g_rgb[ray * 3 + 2]};
+    if (flags & RSN_COMP_CLIP_RGB) {  // torch.clamp backward: pass where min <= x <= max
+      if (!(c0 >= 0.0f && c0 <= 1.0f)) g[0] = 0.0f;
+      if (!(c1 >= 0.0f && c1 <= 1.0f)) g[1] = 0.0f;
+      if (!(c2 >= 0.0f && c2 <= 1.0f)) g[2] = 0.0f;
+    }
+    const float g_r = io.g_roughness ? io.g_roughness[ray] : 0.0f;
+    const float g_a = io.g_accumulation ? io.g_accumulation[ray] : 0.0f;
+    if (lane == 0 && io.g_bg) {
+      io.g_bg[ray * 3 + 0] = g[0] * rem; io.g_bg[ray * 3 + 1] = g[1] * rem; io.g_bg[ray * 3 + 2] = g[2] * rem;
+    }
+    // pass 2: total of g_w[i] * w_i
+    double total = 0.0;
+    if (!detach_weights) {
+      for (int i = lane; i < S; i += 64) {
+        const float w = io.weights[sbase + i];
+        float gw = g[0] * (io.color[(sbase + i) * 3 + 0] - bg[0]) + g[1] * (io.color[(sbase + i) * 3 + 1] - bg[1]) +
+                   g[2] * (io.color[(sbase + i) * 3 + 2] - bg[2]);
+        if (io.roughness) gw += g_r * io.roughness[sbase + i];
+        gw += g_a;
+        total += (double)gw * (double)w;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
+    }
+    // pass 3: per-sample gradients
+    double carry_x = 0.0, carry_p = 0.0;
+    for (int base = 0; base < S; base += 64) {
+      const int i = base + lane;
+      const bool in = i < S;
+      float w = 0.0f, gw = 0.0f, x = 0.0f, delta = 0.0f;
+      if (in) {
+        w = io.weights[sbase + i];
+        delta = bins[i + 1] - bins[i];
+        x = delta * io.sigma[sbase + i];
+        const long long o3 = (sbase + i) * 3;
+        if (io.g_color) { io.g_color[o3 + 0] = w * g[0]; io.g_color[o3 + 1] = w * g[1]; io.g_color[o3 + 2] = w * g[2]; }
+        if (io.g_roughness_sample) io.g_roughness_sample[sbase + i] = w * g_r;
+        gw = g[0] * (io.color[o3 + 0] - bg[0]) + g[1] * (io.color[o3 + 1] - bg[1]) + g[2] * (io.color[o3 + 2] - bg[2]);
+        if (io.roughness) gw += g_r * io.roughness[sbase + i];
+        gw += g_a;
+      }
+      if (!detach_weights && io.g_sigma) {
+        const double xin = wave_scan_incl((double)x, lane) + carry_x;        // sum_{j<=i} x_j
+        const double pin = wave_scan_incl((double)gw * (double)w, lane) + carry_p;
+        carry_x = __shfl(xin, 63, 64);
+        carry_p = __shfl(pin, 63, 64);
+        const float t_next = expf(-(float)xin);
+        const float gx = gw * t_next - (float)(total - pin);
+        if (in) io.g_sigma[sbase + i] = delta * gx;
+      } else if (in && io.g_sigma) {
+        io.g_sigma[sbase + i] = 0.0f;
+      }
+    }
+  }
+}
+
+extern "C" int rsn_composite_backward(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t background,
+                                      int32_t flags, int32_t detach_weights, const rsn_composite_bwd_io* io,
+                                      void* stream) {
+  RSN_REQUIRE(io, RSN_ERR_INVALID_ARGUMENT, "io is NULL");
+  RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
+  RSN_REQUIRE(background >= 0 && background <= 2, RSN_ERR_INVALID_ARGUMENT, "background=%d", background);
+  RSN_REQUIRE(!(flags & RSN_COMP_EVAL), RSN_ERR_INVALID_ARGUMENT, "backward is defined for training mode only");
+  if (n_rays == 0) return RSN_OK;
+  RSN_REQUIRE(io->sigma && io->euclid_bins && io->color && io->weights && io->g_rgb, RSN_ERR_INVALID_ARGUMENT,
+              "sigma/bins/color/weights/g_rgb is NULL");
+  RSN_REQUIRE(background != 2 || io->bg_rgb, RSN_ERR_INVALID_ARGUMENT, "background=2 needs bg_rgb");
+  int blocks = (n_rays + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rsn_composite_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_rays, n_dev,
+                     n_samples, background, flags, detach_weights, *io);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+// column sums (bias gradients): each workgroup owns a chunk of rows, thread t owns columns t, t+256, ...
+__global__ __launch_bounds__(256) void rsn_colsum_kernel(long long n_rows, int n_cols, int ld, const float* x,
+                                                         float* out, long long rows_per_block) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > n_rows) r1 = n_rows;
+  for (int c = threadIdx.x; c < n_cols; c += 256) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    long long r = r0;
+    for (; r + 3 < r1; r += 4) {
+      s0 += x[r * ld + c]; s1 += x[(r + 1) * ld + c]; s2 += x[(r + 2) * ld + c]; s3 += x[(r + 3) * ld + c];
+    }
+    for (; r < r1; ++r) s0 += x[r * ld + c];
+    atomicAdd(&out[c], (s0 + s1) + (s2 + s3));
+  }
+}
+
+extern "C" int rsn_colsum(int64_t n_rows, int32_t n_cols, int32_t ld, const float* x, float* out, int32_t accumulate,
+                          void* stream) {
+  RSN_REQUIRE(n_rows >= 0 && n_cols >= 1 && ld >= n_cols, RSN_ERR_INVALID_ARGUMENT, "n_rows=%lld n_cols=%d ld=%d",
+              (long long)n_rows, n_cols, ld);
+  RSN_REQUIRE(out, RSN_ERR_INVALID_ARGUMENT, "out is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) RSN_HIP(hipMemsetAsync(out, 0, sizeof(float) * n_cols, st));
+  if (n_rows == 0) return RSN_OK;
+  RSN_REQUIRE(x, RSN_ERR_INVALID_ARGUMENT, "x is NULL");
+  const long long rows_per_block = 2048;
+  const long long blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(rsn_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n_rows, n_cols, ld, x, out,
+                     rows_per_block);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+__global__ __launch_bounds__(256) void rsn_ray_sum_kernel(int n_rays, const int* n_dev, int S, const float* x,
+                                                          float* out) {
+  const int R = dyn_count(n_rays, n_dev);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int ray = blockIdx.x * 4 + wid; ray < R; ray += gridDim.x * 4) {
+    float s = 0.0f;
+    for (int i = lane; i < S; i += 64) s += x[(long long)ray * S + i];
+    s = wave_sum(s);
+    if (lane == 0) out[ray] = s;
+  }
+}
+
+extern "C" int rsn_ray_sum(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, const float* x, float* out,
+                           void* stream) {
+  RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
+  if (n_rays == 0) return RSN_OK;
+  RSN_REQUIRE(x && out, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  int blocks = (n_rays + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rsn_ray_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_rays, n_dev, n_samples, x,
+                     out);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+__global__ void rsn_reflect_bwd_kernel(int n_rays, const int* n_masked, const int* ray_index, const float* n_dot_d,
+                                       const float* roughness, const float* g_sq, const float* g_pa, float* g_rough) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_rays) g_rough[i] = 0.0f;
+}
+
+__global__ void rsn_reflect_bwd_scatter_kernel(int n_rays, const int* n_masked, const int* ray_index,
+                                               const float* n_dot_d, const float* roughness, const float* g_sq,
+                                               const float* g_pa, float* g_rough) {
+  const int M = dyn_count(n_rays, n_masked);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int r = ray_index[i];
+  const float gs = (g_sq ? g_sq[i] : 0.0f) + 3.141592653589793f * (g_pa ? g_pa[i] : 0.0f);
+  // sqradius = 2 |n.d| roughness^2
+  g_rough[r] = gs * (2.0f * fabsf(n_dot_d[r])) * (2.0f * roughness[r]);
+}
+
+extern "C" int rsn_reflect_backward(int32_t n_rays, const int32_t* n_masked, const int32_t* ray_index,
+                                    const float* n_dot_d, const float* roughness, const float* g_sqradius,
+                                    const float* g_pixel_area, float* g_roughness, void* stream) {
+  RSN_REQUIRE(n_rays >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
+  if (n_rays == 0) return RSN_OK;
+  RSN_REQUIRE(n_masked && ray_index && n_dot_d && roughness && g_roughness, RSN_ERR_INVALID_ARGUMENT,
+              "a pointer is NULL");
+  const int threads = 256, blocks = (n_rays + threads - 1) / threads;
+  hipLaunchKernelGGL(rsn_reflect_bwd_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_rays, n_masked,
+                     ray_index, n_dot_d, roughness, g_sqradius, g_pixel_area, g_roughness);
+  hipLaunchKernelGGL(rsn_reflect_bwd_scatter_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_rays,
+                     n_masked, ray_index, n_dot_d, roughness, g_sqradius, g_pixel_area, g_roughness);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // reflection rays: mask, stable compaction, secondary-ray construction (model.py:222-229,240-241,267-289).
 // A single 1024-thread workgroup walks the rays in order (block scan per 1024-ray chunk) so the
 // compaction is stable like the reference's boolean-mask gather.
@@ -419,6 +616,57 @@ extern "C" int rsn_reflect_combine(int32_t n_rays_max, const int32_t* n_masked, 
   const int blocks = (n_rays_max * 3 + threads - 1) / threads;
   hipLaunchKernelGGL(rsn_reflect_combine_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_rays_max,
                      n_masked, ray_index, diff, tint, comp, out);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+__global__ void rsn_reflect_combine_bwd_kernel(int n_max, const int* n_masked, const int* ray_index, const float* diff,
+                                               const float* tint, const float* comp, const float* g_out,
+                                               float* g_comp) {
+  const int M = dyn_count(n_max, n_masked);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * 3) return;
+  const int i = e / 3, c = e - i * 3;
+  const int r = ray_index[i];
+  const float v = diff[r * 3 + c] + tint[r * 3 + c] * comp[i * 3 + c];
+  g_comp[i * 3 + c] = (v >= 0.0f && v <= 1.0f) ? g_out[r * 3 + c] * tint[r * 3 + c] : 0.0f;
+}
+
+extern "C" int rsn_reflect_combine_backward(int32_t n_rays_max, const int32_t* n_masked, const int32_t* ray_index,
+                                            const float* diff, const float* tint, const float* comp,
+                                            const float* g_out, float* g_comp, void* stream) {
+  RSN_REQUIRE(n_rays_max >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays_max=%d", n_rays_max);
+  if (n_rays_max == 0) return RSN_OK;
+  RSN_REQUIRE(n_masked && ray_index && diff && tint && comp && g_out && g_comp, RSN_ERR_INVALID_ARGUMENT,
+              "a pointer is NULL");
+  const int threads = 256;
+  const int blocks = (n_rays_max * 3 + threads - 1) / threads;
+  hipLaunchKernelGGL(rsn_reflect_combine_bwd_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_rays_max,
+                     n_masked, ray_index, diff, tint, comp, g_out, g_comp);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+__global__ void rsn_reflect_default_bwd_kernel(int n_rays, const uint8_t* mask, const float* gc, const float* gf,
+                                               float* g_acc) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  float v = 0.0f;
+  if (!mask[r]) {
+    if (gc) v -= gc[r * 3 + 0] + gc[r * 3 + 1] + gc[r * 3 + 2];
+    if (gf) v -= gf[r * 3 + 0] + gf[r * 3 + 1] + gf[r * 3 + 2];
+  }
+  g_acc[r] = v;
+}
+
+extern "C" int rsn_reflect_default_backward(int32_t n_rays, const uint8_t* mask, const float* g_reflect_coarse,
+                                            const float* g_reflect_fine, float* g_accumulation, void* stream) {
+  RSN_REQUIRE(n_rays >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
+  if (n_rays == 0) return RSN_OK;
+  RSN_REQUIRE(mask && g_accumulation, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  const int threads = 256, blocks = (n_rays + threads - 1) / threads;
+  hipLaunchKernelGGL(rsn_reflect_default_bwd_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_rays, mask,
+                     g_reflect_coarse, g_reflect_fine, g_accumulation);
   RSN_HIP(hipGetLastError());
   return RSN_OK;
 }

@@ -102,10 +102,27 @@ class ReflectSamplingNeRFModel(Model):
         if self.field is None:
             raise ValueError("populate_fields() must be called before get_outputs")
         if self.training:
-            raise NotImplementedError(
-                "training-mode get_outputs (stratified jitter, analytic normals, backward) is not built yet on the "
-                "HIP path; call model.eval().  There is deliberately no eager/CPU fallback.")
+            return self._get_outputs_train(ray_bundle)
         return self._get_outputs_eval(ray_bundle)
+
+    def _get_outputs_train(self, ray_bundle, jitter: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+        """Training mode: one autograd node (train_graph.GetOutputsTrain) over the HIP forward/backward kernels.
+        `jitter` optionally injects the samplers' uniform draws (tests share them with the oracle)."""
+        from .train_graph import DIFF_KEYS, GetOutputsTrain
+
+        R = ray_bundle.origins.shape[0]
+        o = ops._f32c(ray_bundle.origins.reshape(R, 3))
+        d = ops._f32c(ray_bundle.directions.reshape(R, 3))
+        pa = ops._f32c(ray_bundle.pixel_area.reshape(R))
+        nears = ops._f32c(ray_bundle.nears.reshape(R))
+        fars = ops._f32c(ray_bundle.fars.reshape(R))
+        outs = GetOutputsTrain.apply(self, o, d, pa, nears, fars, jitter, *self.field.parameters())
+        outputs = dict(zip(DIFF_KEYS, outs))
+        aux = self._train_aux
+        self._train_aux = None
+        for k, v in aux.items():
+            outputs[k] = v.detach() if v.dtype.is_floating_point else v
+        return outputs
 
     @torch.no_grad()
     def _get_outputs_eval(self, ray_bundle) -> Dict[str, Tensor]:

@@ -1,0 +1,339 @@
+"""Training-mode get_outputs as ONE autograd node (reference: reflect_sampling_nerf_model.py:142-344 under
+`self.training`, with torch autograd building the graph op by op).
+
+forward  = samplers (stratified jitter) -> fused field kernels in training mode (activations saved, analytic
+           normals by a dX sweep) -> compositing -> reflected rays (one host sync: M sizes the reflect buffers).
+backward = the same pipeline reversed through librsn_hip.so: reflect combine / composite backward (suffix scan),
+           rsn_field_backward_* (transposed-weight MFMA sweep producing every layer's pre-activation gradient),
+           then the weight gradients dW = dY^T X as plain library GEMMs (torch.mm -> hipBLASLt/rocBLAS) and the
+           bias gradients by rsn_colsum.
+
+Which outputs carry gradient, and the detach points, follow the reference exactly: mid_rgb_*, mid_reflect_*
+(through colour and -- for the primary levels -- through the weights), pred_normals_*, n_dot_d_*, roughness;
+reflect weights, diff/tint (rendered), normals, accumulation, depth and the resampled bins are constants.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor
+
+from . import _abi, ops
+from ._abi import CompositeBwdIO, FieldGradsIn, FieldGradsOut, FieldSaved, check, ptr
+
+ENC_SLOTS = 104
+SH_SLOTS = 40
+
+
+def enc_slot_columns() -> List[int]:
+    """slot k (= it*8 + 4h + s) of the kernel's encoded-input order -> column of the reference's 99-wide
+    NeRFEncoding output, or -1 (padding).  Mirrors csrc/rsn_pack.hip: enc_slot_to_column."""
+    cols = []
+    for k in range(ENC_SLOTS):
+        it, h, s = k >> 3, (k >> 2) & 1, k & 3
+        u = it * 4 + s
+        if u < 24:
+            c = (u // 8) * 16 + 8 * h + (u % 8)
+        elif u < 48:
+            c = 48 + ((u - 24) // 8) * 16 + 8 * h + ((u - 24) % 8)
+        elif u < 51 and h == 0:
+            c = 96 + (u - 48)
+        else:
+            c = -1
+        cols.append(c)
+    return cols
+
+
+def sh_slot_columns() -> List[int]:
+    cols = []
+    for k in range(SH_SLOTS):
+        it, h, s = k >> 3, (k >> 2) & 1, k & 3
+        u = it * 4 + s
+        cols.append(17 * h + u if u < 17 else -1)
+    return cols
+
+
+def _unpermute(g_slots: Tensor, cols: List[int], width: int) -> Tensor:
+    """[out, n_slots] gradient in slot order -> [out, width] in reference column order."""
+    live = [i for i, c in enumerate(cols) if c >= 0]
+    dst = [cols[i] for i in live]
+    out = g_slots.new_zeros(g_slots.shape[0], width)
+    out[:, dst] = g_slots[:, live]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ thin wrappers
+def _composite_backward(n, S, background, flags, detach_w, level, eb, weights, g_rgb, bg=None, g_rough=None,
+                        want_sigma=True, want_bg=False, rough_samples=None, g_acc=None):
+    lib = _abi.load_library()
+    dev = g_rgb.device
+    out = {"g_color": torch.empty(n, S, 3, device=dev)}
+    if want_sigma:
+        out["g_sigma"] = torch.empty(n, S, device=dev)
+    if rough_samples is not None:
+        out["g_rough"] = torch.empty(n, S, device=dev)
+    if want_bg:
+        out["g_bg"] = torch.empty(n, 3, device=dev)
+    io = CompositeBwdIO()
+    io.sigma, io.euclid_bins, io.color, io.bg_rgb = ptr(level["sigma"]), ptr(eb), ptr(level["color"]), ptr(bg)
+    io.roughness, io.weights, io.g_rgb, io.g_roughness = ptr(rough_samples), ptr(weights), ptr(g_rgb), ptr(g_rough)
+    io.g_accumulation = ptr(g_acc)
+    io.g_sigma, io.g_color = ptr(out.get("g_sigma")), ptr(out["g_color"])
+    io.g_roughness_sample, io.g_bg = ptr(out.get("g_rough")), ptr(out.get("g_bg"))
+    check(lib.rsn_composite_backward(n, None, S, background, flags, detach_w, io, ops._stream()))
+    return out
+
+
+def _saved_struct(saved: Dict[str, Tensor]) -> FieldSaved:
+    fs = FieldSaved()
+    for k in ("enc", "act", "bott", "sh", "hid", "heads", "normals"):
+        setattr(fs, k, ptr(saved.get(k)))
+    return fs
+
+
+def _alloc_gout(field, N: int, dev, need_input: bool):
+    W, L = field.width, field.mlp_base.num_layers
+    g = {"dz_rgb": torch.empty(N, 4, device=dev), "da_mid": torch.empty(N, 128, device=dev),
+         "d_bott": torch.empty(N, W, device=dev), "dz_heads": torch.empty(N, 16, device=dev),
+         "dy": torch.empty(L, N, W, device=dev)}
+    if need_input:
+        g["d_input"] = torch.empty(N, device=dev)
+    st = FieldGradsOut()
+    for k in ("dz_rgb", "da_mid", "d_bott", "dz_heads", "dy", "d_input"):
+        setattr(st, k, ptr(g.get(k)))
+    return g, st
+
+
+def _colsum(x: Tensor, n_cols: int) -> Tensor:
+    lib = _abi.load_library()
+    out = torch.empty(n_cols, device=x.device)
+    check(lib.rsn_colsum(x.shape[0], n_cols, x.stride(0), ptr(x), ptr(out), 0, ops._stream()))
+    return out
+
+
+class _GradAcc:
+    """Accumulates parameter gradients by reference state_dict name."""
+
+    def __init__(self):
+        self.g: Dict[str, Tensor] = {}
+
+    def add(self, name: str, val: Tensor):
+        self.g[name] = val if name not in self.g else self.g[name] + val
+
+
+def _weight_grads(field, saved: Dict[str, Tensor], gout: Dict[str, Tensor], acc: _GradAcc, with_heads: bool):
+    """dW = dY^T X for every linear layer of one field evaluation (library GEMMs), db = column sums."""
+    L, W = field.mlp_base.num_layers, field.width
+    skip = field.field_desc().skip_layer
+    enc_cols, sh_cols = enc_slot_columns(), sh_slot_columns()
+    for l in range(L):
+        dy = gout["dy"][l]
+        if l == 0:
+            gw = _unpermute(torch.mm(dy.t(), saved["enc"]), enc_cols, 99)
+        elif l == skip:
+            gw = torch.cat([_unpermute(torch.mm(dy.t(), saved["enc"]), enc_cols, 99),
+                            torch.mm(dy.t(), saved["act"][l - 1])], dim=1)
+        else:
+            gw = torch.mm(dy.t(), saved["act"][l - 1])
+        acc.add(f"mlp_base.layers.{l}.weight", gw)
+        acc.add(f"mlp_base.layers.{l}.bias", _colsum(dy, W))
+    emb = saved["act"][L - 1]
+    acc.add("field_output_bottleneck.net.weight", torch.mm(gout["d_bott"].t(), emb))
+    acc.add("field_output_bottleneck.net.bias", _colsum(gout["d_bott"], W))
+    gm = torch.mm(gout["da_mid"].t(), saved["sh"])
+    acc.add("mlp_mid.layers.0.weight", torch.cat([_unpermute(gm, sh_cols, 34),
+                                                 torch.mm(gout["da_mid"].t(), saved["bott"])], dim=1))
+    acc.add("mlp_mid.layers.0.bias", _colsum(gout["da_mid"], 128))
+    acc.add("field_output_mid.net.weight", torch.mm(gout["dz_rgb"].t(), saved["hid"])[:3])
+    acc.add("field_output_mid.net.bias", _colsum(gout["dz_rgb"], 4)[:3])
+    if with_heads:
+        H = torch.mm(gout["dz_heads"].t(), emb)  # [16, W]
+        hb = _colsum(gout["dz_heads"], 16)
+        for name, lo, hi in (("density", 0, 1), ("normals", 1, 4), ("diff", 4, 7), ("roughness", 8, 9),
+                             ("tint", 12, 15)):
+            acc.add(f"field_output_{name}.net.weight", H[lo:hi])
+            acc.add(f"field_output_{name}.net.bias", hb[lo:hi])
+
+
+def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], need_input: bool):
+    lib = _abi.load_library()
+    o, d, pa = rays
+    n, S = eb.shape[0], eb.shape[1] - 1
+    gout, gst = _alloc_gout(field, n * S, o.device, need_input)
+    gi = FieldGradsIn()
+    for k in ("sigma", "color", "pred_normals", "n_dot_d", "roughness"):
+        setattr(gi, k, ptr(gin.get(k)))
+    fo = ops.field_outputs_struct(level)
+    fs = _saved_struct(level["saved"])
+    desc = field.field_desc()
+    check(lib.rsn_field_backward_frustum(C.byref(desc), ptr(field.packed_weights()), n, None, S, ptr(o), ptr(d),
+                                         ptr(pa), ptr(eb), C.byref(fo), C.byref(fs), C.byref(gi), C.byref(gst),
+                                         1 if need_input else 0, ops._stream()))
+    return gout
+
+
+def _ray_sum(x: Tensor, n: int, S: int) -> Tensor:
+    lib = _abi.load_library()
+    out = torch.empty(n, device=x.device)
+    check(lib.rsn_ray_sum(n, None, S, ptr(x), ptr(out), ops._stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ the autograd node
+DIFF_KEYS = ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "pred_normals_coarse",
+             "pred_normals_fine", "n_dot_d_coarse", "n_dot_d_fine", "roughness")
+
+
+class GetOutputsTrain(torch.autograd.Function):
+    """inputs: (model, ray tensors, jitter dict or None, *field parameters) -> tuple of DIFF_KEYS tensors.
+    The non-differentiable outputs are left on `model._train_aux` by forward."""
+
+    @staticmethod
+    def forward(ctx, model, o, d, pa, nears, fars, jitter, *params):
+        cfg, fld = model.config, model.field
+        R, dev = o.shape[0], o.device
+        Sc, Sf = cfg.num_coarse_samples, cfg.num_importance_samples
+        Src, Srf = cfg.num_reflect_coarse_samples, cfg.num_reflect_importance_samples
+        CLIP = ops.RSN_COMP_CLIP_RGB
+        uni, rec = model.sampler_uniform.spec, model.sampler_reciprocal.spec
+        jitter = jitter or {}
+
+        def jit(name, n, S):
+            t = jitter.get(name)
+            return ops._f32c(t.to(dev)) if t is not None else torch.rand(n, S + 1, device=dev)
+
+        # A. coarse, B. fine (+ per-ray surface attributes)
+        sb_c, eb_c = ops.sample_spaced(R, None, Sc, uni.spacing, uni.tan, nears, fars, jit("coarse", R, Sc))
+        lc = fld.evaluate_frustums_train(o, d, pa, eb_c, want_normals=True)
+        cc = ops.composite(R, None, Sc, 1, CLIP, lc["sigma"], eb_c, lc["color"])
+        sb_f, eb_f = ops.sample_pdf(R, None, Sc, Sf, uni.spacing, uni.tan, model.sampler_pdf.histogram_padding, nears,
+                                    fars, cc["weights"], sb_c, jit("fine", R, Sf))
+        lf = fld.evaluate_frustums_train(o, d, pa, eb_f, want_normals=True)
+        cf = ops.composite(R, None, Sf, 1, CLIP, lf["sigma"], eb_f, lf["color"], level=lf, surface=True)
+        rs = ops.reflect_setup(o, d, cf["accumulation"], cf["depth"], cf["normals"], cf["roughness"], float(model.far))
+        M = int(rs["n_masked"].item())  # training: one sync here sizes the reflect buffers exactly
+
+        aux = {
+            "accumulation_coarse": cc["accumulation"].unsqueeze(-1), "accumulation_fine": cf["accumulation"].unsqueeze(-1),
+            "depth_coarse": cc["depth"].unsqueeze(-1), "depth_fine": cf["depth"].unsqueeze(-1),
+            "weights_coarse": cc["weights"].unsqueeze(-1), "weights_fine": cf["weights"].unsqueeze(-1),
+            "normals_coarse": lc["normals"], "normals_fine": lf["normals"],
+            "diff": cf["diff"], "tint": cf["tint"], "mask": rs["mask"].bool(),
+        }
+        st = dict(R=R, M=M, eb_c=eb_c, eb_f=eb_f, lc=lc, lf=lf, cc=cc, cf=cf, rs=rs, rays=(o, d, pa))
+        if M > 0:
+            o2, d2 = rs["origins2"][:M].contiguous(), rs["directions2"][:M].contiguous()
+            pa2, sq = rs["pixel_area2"][:M].contiguous(), rs["sqradius"][:M].contiguous()
+            near2, far2 = rs["nears2"][:M].contiguous(), rs["fars2"][:M].contiguous()
+            nm = rs["n_masked"]
+            lib = _abi.load_library()
+            # get_inf_color in training mode (activations saved)
+            W, L = fld.width, fld.mlp_base.num_layers
+            f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+            inf_saved = {"enc": f(M, 104), "act": f(L, M, W), "bott": f(M, W), "sh": f(M, 40), "hid": f(M, 128),
+                         "heads": f(M, 8)}
+            bg = f(M, 3)
+            desc = fld.field_desc()
+            fs = _saved_struct(inf_saved)
+            check(lib.rsn_field_forward_inf_train(C.byref(desc), ptr(fld.packed_weights()), M, None, ptr(d2), ptr(sq),
+                                                  ptr(bg), C.byref(fs), ops._stream()))
+            sb_rc, eb_rc = ops.sample_spaced(M, None, Src, rec.spacing, rec.tan, near2, far2,
+                                             jit("reflect_coarse", M, Src))
+            lrc = fld.evaluate_frustums_train(o2, d2, pa2, eb_rc, want_normals=False)
+            crc = ops.composite(M, None, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
+            ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
+            sb_rf, eb_rf = ops.sample_pdf(M, None, Src, Srf, rec.spacing, rec.tan,
+                                          model.sampler_reflect_pdf.histogram_padding, near2, far2, crc["weights"],
+                                          sb_rc, jit("reflect_fine", M, Srf))
+            lrf = fld.evaluate_frustums_train(o2, d2, pa2, eb_rf, want_normals=False)
+            crf = ops.composite(M, None, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
+            ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
+            aux["depth_reflect_fine"] = crf["depth"].unsqueeze(-1)
+            st.update(rays2=(o2, d2, pa2), sq=sq, bg=bg, inf_saved=inf_saved, eb_rc=eb_rc, eb_rf=eb_rf, lrc=lrc, lrf=lrf,
+                      crc=crc, crf=crf)
+        ctx.st = st
+        ctx.model = model
+        ctx.n_params = len(params)
+        model._train_aux = aux
+        outs = (cc["rgb"], cf["rgb"], rs["reflect_coarse"], rs["reflect_fine"], lc["pred_normals"], lf["pred_normals"],
+                lc["n_dot_d"].unsqueeze(-1), lf["n_dot_d"].unsqueeze(-1), cf["roughness"].unsqueeze(-1))
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb_c, g_rgb_f, g_refl_c, g_refl_f, g_pn_c, g_pn_f, g_ndd_c, g_ndd_f, g_rough):
+        st, model = ctx.st, ctx.model
+        fld = model.field
+        lib = _abi.load_library()
+        R, M = st["R"], st["M"]
+        dev = st["rays"][0].device
+        CLIP = ops.RSN_COMP_CLIP_RGB
+        cfg = model.config
+        Sc, Sf = cfg.num_coarse_samples, cfg.num_importance_samples
+        Src, Srf = cfg.num_reflect_coarse_samples, cfg.num_reflect_importance_samples
+        z = lambda g, *shape: ops._f32c(g) if g is not None else torch.zeros(*shape, device=dev)  # noqa: E731
+        g_rgb_c, g_rgb_f = z(g_rgb_c, R, 3), z(g_rgb_f, R, 3)
+        g_refl_c, g_refl_f = z(g_refl_c, R, 3), z(g_refl_f, R, 3)
+        acc = _GradAcc()
+        cf, rs = st["cf"], st["rs"]
+        g_rough_ray = z(g_rough, R, 1).reshape(R).clone()
+
+        if M > 0:
+            nm = rs["n_masked"]
+            g_bg = torch.zeros(M, 3, device=dev)
+            g_pa2 = torch.zeros(M, device=dev)
+            for eb, lv, cp, g_out, S in ((st["eb_rf"], st["lrf"], st["crf"], g_refl_f, Srf),
+                                         (st["eb_rc"], st["lrc"], st["crc"], g_refl_c, Src)):
+                g_comp = torch.empty(M, 3, device=dev)
+                check(lib.rsn_reflect_combine_backward(M, ptr(nm), ptr(rs["ray_index"]), ptr(cf["diff"]), ptr(cf["tint"]),
+                                                       ptr(cp["rgb"]), ptr(g_out), ptr(g_comp), ops._stream()))
+                cb = _composite_backward(M, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
+                                         want_bg=True)
+                g_bg += cb["g_bg"]
+                gout = _field_backward(fld, st["rays2"], eb, lv, {"color": cb["g_color"]}, need_input=True)
+                g_pa2 += _ray_sum(gout["d_input"], M, S)
+                _weight_grads(fld, lv["saved"], gout, acc, with_heads=True)
+                del gout
+            # get_inf_color
+            gout, gst = _alloc_gout(fld, M, dev, True)
+            desc = fld.field_desc()
+            fs = _saved_struct(st["inf_saved"])
+            check(lib.rsn_field_backward_inf(C.byref(desc), ptr(fld.packed_weights()), M, None, ptr(st["rays2"][1]),
+                                             ptr(st["sq"]), C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream()))
+            _weight_grads(fld, st["inf_saved"], gout, acc, with_heads=False)
+            g_r = torch.empty(R, device=dev)
+            check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
+                                           ptr(gout["d_input"]), ptr(g_pa2), ptr(g_r), ops._stream()))
+            g_rough_ray += g_r
+            del gout
+
+        # fine primary level (+ the live accumulation of the non-reflected rays' default reflect colour)
+        lf = st["lf"]
+        g_acc = torch.empty(R, device=dev)
+        check(lib.rsn_reflect_default_backward(R, ptr(rs["mask"]), ptr(g_refl_c), ptr(g_refl_f), ptr(g_acc),
+                                               ops._stream()))
+        cb = _composite_backward(R, Sf, 1, CLIP, 0, lf, st["eb_f"], cf["weights"], g_rgb_f, g_rough=g_rough_ray,
+                                 rough_samples=lf["roughness"], g_acc=g_acc)
+        gin = {"sigma": cb["g_sigma"], "color": cb["g_color"], "roughness": cb["g_rough"],
+               "pred_normals": ops._f32c(g_pn_f) if g_pn_f is not None else None,
+               "n_dot_d": ops._f32c(g_ndd_f.reshape(R, Sf)) if g_ndd_f is not None else None}
+        gout = _field_backward(fld, st["rays"], st["eb_f"], lf, gin, need_input=False)
+        _weight_grads(fld, lf["saved"], gout, acc, with_heads=True)
+        del gout
+        # coarse primary level
+        lc, cc = st["lc"], st["cc"]
+        cb = _composite_backward(R, Sc, 1, CLIP, 0, lc, st["eb_c"], cc["weights"], g_rgb_c)
+        gin = {"sigma": cb["g_sigma"], "color": cb["g_color"],
+               "pred_normals": ops._f32c(g_pn_c) if g_pn_c is not None else None,
+               "n_dot_d": ops._f32c(g_ndd_c.reshape(R, Sc)) if g_ndd_c is not None else None}
+        gout = _field_backward(fld, st["rays"], st["eb_c"], lc, gin, need_input=False)
+        _weight_grads(fld, lc["saved"], gout, acc, with_heads=True)
+        del gout
+
+        grads = []
+        for name, p in fld.named_parameters():
+            g = acc.g.get(name)
+            grads.append(g.reshape(p.shape) if g is not None else None)  # field_output_low: unused -> None
+        ctx.st = None
+        return (None,) * 7 + tuple(grads)

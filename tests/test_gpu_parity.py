@@ -318,3 +318,120 @@ def test_train_level_normals_and_saved_activations(dev, layers, width):
     assert max_abs(n_gpu, n_ref) <= TOL_GRAD_NORMAL
     assert float((n_gpu - n_ref).abs().mean()) <= 5e-5
     assert float((n_gpu.norm(dim=-1) - 1).abs().max()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- training: forward + backward
+def _loss_from_outputs(out, tgt):
+    """A loss touching every gradient-carrying output, shaped like get_loss_dict (model.py:395-407)."""
+    loss = 0.0
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine"):
+        loss = loss + torch.mean((out[k] - tgt[k]) ** 2)
+    for lvl, c1, c2 in (("coarse", 3e-3, 1e-2), ("fine", 3e-3, 1e-1)):
+        w = out[f"weights_{lvl}"].detach()
+        loss = loss + c1 * torch.sum(w * torch.sum((out[f"normals_{lvl}"].detach() - out[f"pred_normals_{lvl}"]) ** 2,
+                                                   dim=-1, keepdim=True))
+        loss = loss + c2 * torch.sum(w * torch.clamp(out[f"n_dot_d_{lvl}"], min=0.0) ** 2)
+    return loss
+
+
+def _coarse_loss(out, tgt):
+    w = out["weights_coarse"].detach()
+    return (torch.mean((out["mid_rgb_coarse"] - tgt["mid_rgb_coarse"]) ** 2)
+            + 3e-3 * torch.sum(w * torch.sum((out["normals_coarse"].detach() - out["pred_normals_coarse"]) ** 2, dim=-1,
+                                             keepdim=True))
+            + 1e-2 * torch.sum(w * torch.clamp(out["n_dot_d_coarse"], min=0.0) ** 2))
+
+
+@pytest.mark.parametrize("layers,width,samples,R,bias", [
+    (8, 64, (16, 16, 8, 8), 48, 2.0),
+    (8, 128, (32, 24, 16, 12), 37, 1.5),
+    (4, 64, (16, 16, 8, 8), 40, 2.0),
+])
+def test_train_forward_backward_matches_oracle_autograd(dev, layers, width, samples, R, bias):
+    """Training-mode get_outputs (stratified jitter, analytic normals) and its backward against autograd through the
+    oracle, with the samplers' uniform draws shared.
+
+    Two losses.  (a) coarse-level terms only: the coarse samples are bit-identical in both pipelines, so every
+    parameter gradient must agree tightly (2e-4 of the tensor's largest entry).  (b) the full loss (all four colour
+    terms, both normal losses, both orientation losses): the resampled fine/reflect positions agree to ~1e-6 only
+    (CDF scan order), the IPE amplifies that by up to ~3e3 and a small fraction of near-zero ReLU units flips, which
+    changes a gradient discontinuously -- so (b) checks direction (cosine >= 0.999) and relative L2 (<= 3e-2) per
+    tensor, and the head / mid-MLP gradients (which see no flips below them) tightly."""
+    seed = layers * 7 + width
+    torch.manual_seed(seed)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(
+        num_coarse_samples=samples[0], num_importance_samples=samples[1], num_reflect_coarse_samples=samples[2],
+        num_reflect_importance_samples=samples[3], base_mlp_num_layers=layers, base_mlp_layer_width=width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += bias
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.field.state_dict().items()}
+    model.to(dev).train()
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=seed + 50)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    fs, ms = cpu_ref.FieldSpec(num_layers=layers, width=width), cpu_ref.ModelSpec(*samples)
+    g = torch.Generator().manual_seed(seed + 1)
+    jit = {"coarse": torch.rand(R, samples[0] + 1, generator=g), "fine": torch.rand(R, samples[1] + 1, generator=g),
+           "reflect_coarse": torch.rand(R, samples[2] + 1, generator=g),
+           "reflect_fine": torch.rand(R, samples[3] + 1, generator=g)}
+    tgt = {k: torch.rand(R, 3, generator=g) for k in ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse",
+                                                      "mid_reflect_fine")}
+    tgt_dev = {k: v.to(dev) for k, v in tgt.items()}
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev), nears=nears.to(dev),
+                       fars=fars.to(dev))
+
+    def run(loss_fn, share_normals):
+        for p in P.values():
+            p.grad = None
+        model.zero_grad(set_to_none=True)
+        ref = cpu_ref.get_outputs(P, fs, ms, o, d, pa, nears, fars, training=True, jitter=jit)
+        loss_fn(ref, tgt).backward()
+        M = int(ref["mask"].sum())
+        assert M > 0
+        jit_gpu = dict(jit, reflect_coarse=jit["reflect_coarse"][ref["mask"]],
+                       reflect_fine=jit["reflect_fine"][ref["mask"]])
+        out = model._get_outputs_train(rb, jitter=jit_gpu)
+        checked = dict(out)
+        if share_normals:  # the analytic normals are a detached loss target: give both sides the same constant
+            checked["normals_coarse"] = ref["normals_coarse"].detach().to(dev)
+            checked["normals_fine"] = ref["normals_fine"].detach().to(dev)
+        loss_fn(checked, tgt_dev).backward()
+        torch.cuda.synchronize()
+        return ref, out
+
+    # ---- forward values + (a) coarse-only loss: tight
+    ref, out = run(_coarse_loss, share_normals=True)
+    assert set(out.keys()) == set(ref.keys())
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "accumulation_coarse",
+              "accumulation_fine", "weights_coarse", "weights_fine", "diff", "tint", "roughness"):
+        assert max_abs(out[k].detach().cpu(), ref[k].detach()) <= TOL, k
+    for k in ("pred_normals_coarse", "pred_normals_fine", "n_dot_d_coarse", "n_dot_d_fine"):
+        assert max_abs(out[k].detach().cpu(), ref[k].detach()) <= TOL_UNIT, k
+    assert torch.equal(out["mask"].cpu(), ref["mask"])
+    assert out["depth_reflect_fine"].shape == ref["depth_reflect_fine"].shape
+    for lvl in ("coarse", "fine"):  # analytic normals: ill-conditioned where the raw gradient is tiny
+        e = (out[f"normals_{lvl}"].cpu() - ref[f"normals_{lvl}"]).abs()
+        assert float(e.mean()) <= 1e-3 and float(e.flatten().quantile(0.99)) <= 5e-3, lvl
+    for name, p in model.field.named_parameters():
+        gr = P[name].grad
+        if gr is None or float(gr.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) <= 1e-12, name
+            continue
+        scale = float(gr.abs().max())
+        err = float((p.grad.cpu() - gr).abs().max())
+        assert err <= 2e-4 * scale + 1e-9, f"coarse loss, {name}: abs err {err:.3e}, scale {scale:.3e}"
+
+    # ---- (b) full loss
+    run(_loss_from_outputs, share_normals=True)
+    for name, p in model.field.named_parameters():
+        gr = P[name].grad
+        if "field_output_low" in name:
+            assert p.grad is None and gr is None
+            continue
+        assert p.grad is not None, name
+        a, b = p.grad.cpu().flatten().double(), gr.flatten().double()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+        rel = float((a - b).norm() / (b.norm() + 1e-300))
+        assert cos >= 0.999 and rel <= 3e-2, f"full loss, {name}: cos {cos:.6f} rel-L2 {rel:.3e}"
+        if not name.startswith("mlp_base") or name.startswith(f"mlp_base.layers.{layers - 1}."):
+            assert rel <= 2e-3, f"full loss, {name}: rel-L2 {rel:.3e}"
