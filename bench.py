@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--width", type=int, default=256)
-    ap.add_argument("--workload", default="level", choices=["level", "get_outputs"],
+    ap.add_argument("--workload", default="level", choices=["level", "get_outputs", "train"],
                     help="level = BASELINE configs[1] (default); get_outputs = full eval get_outputs "
-                         "(coarse+fine+reflect), reported for information")
+                         "(coarse+fine+reflect); train = BASELINE configs[2]: full training step (forward, loss, "
+                         "backward, gradient all-reduce, RAdam) with 64 coarse + 128 fine + reflect 64+64 samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -111,13 +112,19 @@ def main():
     pkg.load_library()
     torch.manual_seed(0)  # identical random-init weights on every rank (data parallel replicas)
     R, S = args.rays, args.samples
-    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S, num_importance_samples=S,
-                                            base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
+    if args.workload == "train":
+        cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=64, num_importance_samples=128,
+                                                base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
+    else:
+        cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S, num_importance_samples=S,
+                                                base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
     model = cfg.setup(scene_box=None, num_train_data=1)
-    if args.workload == "get_outputs":
+    if args.workload in ("get_outputs", "train"):
         with torch.no_grad():
             model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised
     model.to(dev).eval()
+    if args.workload == "train":
+        model.train()
     fld = model.field
     o, d, pa = synthetic_rays(R, seed=rank)  # each rank renders its own rays
     o, d, pa = o.to(dev), d.to(dev), pa.reshape(R).to(dev)
@@ -129,7 +136,21 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     state = {}
 
+    if args.workload == "train":
+        from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, train_step
+
+        params = model.get_param_groups()["fields"]
+        optimizer = torch.optim.RAdam(params, lr=1e-3, eps=1e-15)  # reference config.py:50-53
+        reducer = FlatGradAllReduce(params) if world > 1 else None
+        g = torch.Generator().manual_seed(1234 + rank)
+        batch = {"image": torch.rand(R, 3, generator=g).to(dev)}
+        state["it"] = 100  # past the 50-step loss warm-up: all twelve loss terms are live
+
     def step(i=None):
+        if args.workload == "train":
+            state["loss"] = train_step(model, rb, batch, optimizer, reducer, state["it"])
+            state["it"] += 1
+            return
         if args.workload == "get_outputs":
             state["out"] = model(rb)
             return
@@ -160,6 +181,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.workload != "level":
+        with torch.no_grad():
+            model.eval()
+            state["mask_frac"] = float(model(rb)["mask"].float().mean())
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * R * args.steps / elapsed
@@ -180,12 +205,16 @@ def main():
                 "workload": ("BASELINE configs[1]: %d rays x %d samples, %d-layer %d-wide MLP, fp32, fused forward + "
                              "composite of one sampling level (eval)" % (R, S, args.layers, args.width))
                 if args.workload == "level" else
-                ("full eval get_outputs: %d rays x (%d coarse + %d fine + reflect %d + %d), %dx%d field" %
-                 (R, S, S, cfg.num_reflect_coarse_samples, cfg.num_reflect_importance_samples, args.layers,
-                  args.width)),
+                ("full %s: %d rays x (%d coarse + %d fine + reflect %d + %d), %dx%d field, M/R=%.2f" %
+                 ("training step (forward+loss+backward+grad all-reduce+RAdam, BASELINE configs[2])"
+                  if args.workload == "train" else "eval get_outputs",
+                  R, cfg.num_coarse_samples, cfg.num_importance_samples, cfg.num_reflect_coarse_samples,
+                  cfg.num_reflect_importance_samples, args.layers, args.width,
+                  float(state.get("mask_frac", float("nan"))))),
                 "rays_per_gpu": R,
                 "samples_per_ray": S,
-                "parallelism": "dp%d (independent ray batches, no data-path collective)" % world,
+                "parallelism": ("dp%d (independent ray batches, no data-path collective)" % world) if args.workload != "train"
+                else ("dp%d (one flat %d-float gradient all-reduce per step over RCCL)" % (world, 618513)),
                 "weights": "random-init (nn.Linear default), seed 0",
             },
         }

@@ -261,6 +261,13 @@ typedef struct rsn_composite_bwd_io {
 int rsn_composite_backward(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t background, int32_t flags,
                            int32_t detach_weights, const rsn_composite_bwd_io* io, void* stream);
 
+/* rsn_weight_grad: dW[n][col_map ? col_map[k] : k] += sum_m dY[m][n] * X[m][k]  and  db[n] += sum_m dY[m][n]
+ * (n < n_out <= 256, k < k_in <= 256; entries with col_map[k] < 0 are dropped).  The weight-gradient GEMM of
+ * every linear layer of the Field: a reduction over all N sample points with the output tile stationary in MFMA
+ * accumulators.  dW / db are ACCUMULATED (the caller zeroes them once per step); row-major, leading dims in floats. */
+int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x, int32_t ld_x,
+                    int32_t k_in, const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream);
+
 /* rsn_colsum: out[c] (+)= sum_r x[r*ld + c], c < n_cols (bias gradients = column sums of dY). */
 int rsn_colsum(int64_t n_rows, int32_t n_cols, int32_t ld, const float* x, float* out, int32_t accumulate,
                void* stream);

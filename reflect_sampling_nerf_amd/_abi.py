@@ -104,6 +104,8 @@ _SIGNATURES = {
                                          _fp, C.POINTER(FieldGradsOut), C.c_int32, C.c_void_p]),
     "rsn_composite_backward": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(CompositeBwdIO), C.c_void_p]),
+    "rsn_weight_grad": (C.c_int, [C.c_int64, _fp, C.c_int32, C.c_int32, _fp, C.c_int32, C.c_int32, _fp, _fp, C.c_int32,
+                                  _fp, C.c_void_p]),
     "rsn_colsum": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _fp, _fp, C.c_int32, C.c_void_p]),
     "rsn_ray_sum": (C.c_int, [C.c_int32, _fp, C.c_int32, _fp, _fp, C.c_void_p]),
     "rsn_reflect_backward": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),

@@ -5,8 +5,8 @@ forward  = samplers (stratified jitter) -> fused field kernels in training mode 
            normals by a dX sweep) -> compositing -> reflected rays (one host sync: M sizes the reflect buffers).
 backward = the same pipeline reversed through librsn_hip.so: reflect combine / composite backward (suffix scan),
            rsn_field_backward_* (transposed-weight MFMA sweep producing every layer's pre-activation gradient),
-           then the weight gradients dW = dY^T X as plain library GEMMs (torch.mm -> hipBLASLt/rocBLAS) and the
-           bias gradients by rsn_colsum.
+           then rsn_weight_grad: dW = dY^T X and db for every linear layer (output-stationary MFMA reduction over
+           all samples), accumulated straight into nn.Linear-layout gradient tensors.
 
 Which outputs carry gradient, and the detach points, follow the reference exactly: mid_rgb_*, mid_reflect_*
 (through colour and -- for the primary levels -- through the weights), pred_normals_*, n_dot_d_*, roughness;
@@ -106,55 +106,62 @@ def _alloc_gout(field, N: int, dev, need_input: bool):
     return g, st
 
 
-def _colsum(x: Tensor, n_cols: int) -> Tensor:
-    lib = _abi.load_library()
-    out = torch.empty(n_cols, device=x.device)
-    check(lib.rsn_colsum(x.shape[0], n_cols, x.stride(0), ptr(x), ptr(out), 0, ops._stream()))
-    return out
-
-
 class _GradAcc:
-    """Accumulates parameter gradients by reference state_dict name."""
+    """Zero-initialised parameter gradients (nn.Linear layout, reference state_dict names) that rsn_weight_grad
+    accumulates into across the five field evaluations of one step."""
 
-    def __init__(self):
-        self.g: Dict[str, Tensor] = {}
+    def __init__(self, field):
+        self.field = field
+        dev = next(field.parameters()).device
+        self.g: Dict[str, Tensor] = {n: torch.zeros_like(p) for n, p in field.named_parameters()
+                                     if "field_output_low" not in n}
+        W = field.width
+        self.heads_w = torch.zeros(16, W, device=dev)  # rows: 0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint
+        self.heads_b = torch.zeros(16, device=dev)
+        if not hasattr(field, "_enc_col_map") or field._enc_col_map.device != dev:
+            field._enc_col_map = torch.tensor(enc_slot_columns(), dtype=torch.int32, device=dev)
+            field._sh_col_map = torch.tensor(sh_slot_columns(), dtype=torch.int32, device=dev)
 
-    def add(self, name: str, val: Tensor):
-        self.g[name] = val if name not in self.g else self.g[name] + val
+    def finish(self) -> Dict[str, Tensor]:
+        for name, lo, hi in (("density", 0, 1), ("normals", 1, 4), ("diff", 4, 7), ("roughness", 8, 9),
+                             ("tint", 12, 15)):
+            self.g[f"field_output_{name}.net.weight"] += self.heads_w[lo:hi]
+            self.g[f"field_output_{name}.net.bias"] += self.heads_b[lo:hi]
+        return self.g
+
+
+def _wgrad(dy: Tensor, n_out: int, x: Tensor, k_in: int, dw: Tensor, dw_col0: int, db: Optional[Tensor],
+           col_map: Optional[Tensor] = None):
+    """dw[:, dw_col0 + (col_map[k] or k)] += dy[:, :n_out]^T x[:, :k_in];  db += column sums of dy."""
+    lib = _abi.load_library()
+    dwp = C.c_void_p(dw.data_ptr() + 4 * dw_col0)
+    check(lib.rsn_weight_grad(dy.shape[0], ptr(dy), dy.stride(0), n_out, ptr(x), x.stride(0), k_in, ptr(col_map), dwp,
+                              dw.stride(0), ptr(db), ops._stream()))
 
 
 def _weight_grads(field, saved: Dict[str, Tensor], gout: Dict[str, Tensor], acc: _GradAcc, with_heads: bool):
-    """dW = dY^T X for every linear layer of one field evaluation (library GEMMs), db = column sums."""
+    """dW = dY^T X (+ db) for every linear layer of one field evaluation: rsn_weight_grad, accumulated in place."""
     L, W = field.mlp_base.num_layers, field.width
     skip = field.field_desc().skip_layer
-    enc_cols, sh_cols = enc_slot_columns(), sh_slot_columns()
+    enc_map, sh_map = field._enc_col_map, field._sh_col_map
+    g = acc.g
     for l in range(L):
         dy = gout["dy"][l]
+        gw, gb = g[f"mlp_base.layers.{l}.weight"], g[f"mlp_base.layers.{l}.bias"]
         if l == 0:
-            gw = _unpermute(torch.mm(dy.t(), saved["enc"]), enc_cols, 99)
+            _wgrad(dy, W, saved["enc"], ENC_SLOTS, gw, 0, gb, enc_map)
         elif l == skip:
-            gw = torch.cat([_unpermute(torch.mm(dy.t(), saved["enc"]), enc_cols, 99),
-                            torch.mm(dy.t(), saved["act"][l - 1])], dim=1)
+            _wgrad(dy, W, saved["enc"], ENC_SLOTS, gw, 0, gb, enc_map)
+            _wgrad(dy, W, saved["act"][l - 1], W, gw, 99, None)
         else:
-            gw = torch.mm(dy.t(), saved["act"][l - 1])
-        acc.add(f"mlp_base.layers.{l}.weight", gw)
-        acc.add(f"mlp_base.layers.{l}.bias", _colsum(dy, W))
+            _wgrad(dy, W, saved["act"][l - 1], W, gw, 0, gb)
     emb = saved["act"][L - 1]
-    acc.add("field_output_bottleneck.net.weight", torch.mm(gout["d_bott"].t(), emb))
-    acc.add("field_output_bottleneck.net.bias", _colsum(gout["d_bott"], W))
-    gm = torch.mm(gout["da_mid"].t(), saved["sh"])
-    acc.add("mlp_mid.layers.0.weight", torch.cat([_unpermute(gm, sh_cols, 34),
-                                                 torch.mm(gout["da_mid"].t(), saved["bott"])], dim=1))
-    acc.add("mlp_mid.layers.0.bias", _colsum(gout["da_mid"], 128))
-    acc.add("field_output_mid.net.weight", torch.mm(gout["dz_rgb"].t(), saved["hid"])[:3])
-    acc.add("field_output_mid.net.bias", _colsum(gout["dz_rgb"], 4)[:3])
+    _wgrad(gout["d_bott"], W, emb, W, g["field_output_bottleneck.net.weight"], 0, g["field_output_bottleneck.net.bias"])
+    _wgrad(gout["da_mid"], 128, saved["sh"], SH_SLOTS, g["mlp_mid.layers.0.weight"], 0, g["mlp_mid.layers.0.bias"], sh_map)
+    _wgrad(gout["da_mid"], 128, saved["bott"], W, g["mlp_mid.layers.0.weight"], 34, None)
+    _wgrad(gout["dz_rgb"], 3, saved["hid"], 128, g["field_output_mid.net.weight"], 0, g["field_output_mid.net.bias"])
     if with_heads:
-        H = torch.mm(gout["dz_heads"].t(), emb)  # [16, W]
-        hb = _colsum(gout["dz_heads"], 16)
-        for name, lo, hi in (("density", 0, 1), ("normals", 1, 4), ("diff", 4, 7), ("roughness", 8, 9),
-                             ("tint", 12, 15)):
-            acc.add(f"field_output_{name}.net.weight", H[lo:hi])
-            acc.add(f"field_output_{name}.net.bias", hb[lo:hi])
+        _wgrad(gout["dz_heads"], 16, emb, W, acc.heads_w, 0, acc.heads_b)
 
 
 def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], need_input: bool):
@@ -275,7 +282,7 @@ class GetOutputsTrain(torch.autograd.Function):
         z = lambda g, *shape: ops._f32c(g) if g is not None else torch.zeros(*shape, device=dev)  # noqa: E731
         g_rgb_c, g_rgb_f = z(g_rgb_c, R, 3), z(g_rgb_f, R, 3)
         g_refl_c, g_refl_f = z(g_refl_c, R, 3), z(g_refl_f, R, 3)
-        acc = _GradAcc()
+        acc = _GradAcc(fld)
         cf, rs = st["cf"], st["rs"]
         g_rough_ray = z(g_rough, R, 1).reshape(R).clone()
 
@@ -331,9 +338,7 @@ class GetOutputsTrain(torch.autograd.Function):
         _weight_grads(fld, lc["saved"], gout, acc, with_heads=True)
         del gout
 
-        grads = []
-        for name, p in fld.named_parameters():
-            g = acc.g.get(name)
-            grads.append(g.reshape(p.shape) if g is not None else None)  # field_output_low: unused -> None
+        final = acc.finish()
+        grads = [final.get(name) for name, _ in fld.named_parameters()]  # field_output_low: unused -> None
         ctx.st = None
         return (None,) * 7 + tuple(grads)

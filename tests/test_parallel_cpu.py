@@ -1,0 +1,66 @@
+"""world_size-2 gloo test (CPU) of the data-parallel gradient average: equals DDP's mean over ranks, tolerates
+parameters without gradient on one rank, leaves globally-unused parameters at grad=None."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, apply_loss_warmup
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)),
+              torch.nn.Parameter(torch.randn(2, 2)), torch.nn.Parameter(torch.randn(4))]
+    g = torch.Generator().manual_seed(100 + rank)
+    params[0].grad = torch.randn(5, 3, generator=g)
+    params[1].grad = torch.randn(7, generator=g)
+    if rank == 0:  # parameter 2 only receives a gradient on rank 0 (reflect branch skipped on rank 1)
+        params[2].grad = torch.randn(2, 2, generator=g)
+    # parameter 3 is unused everywhere (field_output_low)
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    FlatGradAllReduce(params)()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    ok = True
+    for i, p in enumerate(params):
+        gs = [gg[i] for gg in gathered]
+        if all(x is None for x in gs):
+            ok &= p.grad is None
+        else:
+            mean = sum(torch.zeros_like(p) if x is None else x for x in gs) / world
+            ok &= p.grad is not None and torch.allclose(p.grad, mean, atol=1e-7)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_gloo_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_loss_warmup_schedule():
+    class M:
+        class config:
+            loss_coefficients = {"predicted_normal_loss_coarse": 3e-5, "predicted_normal_loss_fine": 3e-4,
+                                 "orientation_loss_coarse": 1e-2, "orientation_loss_fine": 1e-1, "loss_mid_fine": 1.0}
+
+    apply_loss_warmup(M, 0)
+    assert M.config.loss_coefficients["orientation_loss_fine"] == 0.0 and M.config.loss_coefficients["loss_mid_fine"] == 1.0
+    apply_loss_warmup(M, 50)
+    assert M.config.loss_coefficients["predicted_normal_loss_fine"] == 3e-4
+    assert M.config.loss_coefficients["orientation_loss_coarse"] == 1e-2
