@@ -29,7 +29,8 @@ struct WGradArgs {
 
 template <int NKB>  // input-column blocks of 32 held per wave (8 covers k_in <= 256)
 __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar loop control
   const int i = lane & 31, h = lane >> 5;
   // Waves are assigned (row-block pair, point sub-chunk): P = pairs of 32-row blocks the output needs (1, 2 or 4);
   // the 4/P waves that share a pair split the workgroup's chunk of points, so narrow outputs (heads, RGB head,
@@ -55,16 +56,38 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
       for (int r = 0; r < 16; ++r) acc[t][kb][r] = 0.0f;
   float bsum[2] = {0.0f, 0.0f};
 
-  const bool row_ok[2] = {(nb0 + 0) * 32 + i < a.n_out, (nb0 + 1) * 32 + i < a.n_out};
-  bool col_ok[NKB];
+  // Lane columns are clamped into range instead of masked: a lane whose output row / input column does not exist
+  // works on a duplicate of the last valid one and its results are never flushed.  Nothing in the main loop
+  // touches a loaded value before the MFMAs do, so the loads of stage s+1 stay in flight under the MFMAs of stage s.
+  int cdy[2], cx[NKB];
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb) col_ok[kb] = kb * 32 + i < a.k_in;
-  const float* __restrict__ dyp = a.dy + (nb0 * 32 + i);
-  const float* __restrict__ xp = a.x + i;
+  for (int t = 0; t < 2; ++t) {
+    const int c = (nb0 + t) * 32 + i;
+    cdy[t] = c < a.n_out ? c : a.n_out - 1;
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int c = kb * 32 + i;
+    cx[kb] = c < a.k_in ? c : a.k_in - 1;
+  }
+  const float* __restrict__ dyp = a.dy;
+  const float* __restrict__ xp = a.x;
 
   float fa[2][WG_PAIRS][2], fb[2][WG_PAIRS][NKB];  // [buffer][pair][block]
 
-  auto load_stage = [&](int buf, long long m0) {
+  auto load_stage = [&](int buf, long long m0) {  // all 2*WG_PAIRS points of the stage are in range
+#pragma unroll
+    for (int p = 0; p < WG_PAIRS; ++p) {
+      const long long m = m0 + 2 * p + h;
+      const float* __restrict__ dr = dyp + m * a.ld_dy;
+      const float* __restrict__ xr = xp + m * a.ld_x;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fa[buf][p][t] = dr[cdy[t]];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) fb[buf][p][kb] = xr[cx[kb]];
+    }
+  };
+  auto load_stage_tail = [&](int buf, long long m0) {  // points beyond m_end contribute zeros
 #pragma unroll
     for (int p = 0; p < WG_PAIRS; ++p) {
       const long long m = m0 + 2 * p + h;
@@ -72,12 +95,12 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
       const long long mc = in ? m : m_begin;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const float v = row_ok[t] ? dyp[mc * a.ld_dy + t * 32] : 0.0f;
+        const float v = dyp[mc * a.ld_dy + cdy[t]];
         fa[buf][p][t] = in ? v : 0.0f;
       }
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
-        const float v = col_ok[kb] ? xp[mc * a.ld_x + kb * 32] : 0.0f;
+        const float v = xp[mc * a.ld_x + cx[kb]];
         fb[buf][p][kb] = in ? v : 0.0f;
       }
     }
@@ -97,20 +120,24 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   };
 
   const long long step = 2 * WG_PAIRS;
-  long long m0 = m_begin;
-  load_stage(0, m0);
+  const long long n_full = (m_end - m_begin) / step;  // stages with every point in range
+  if (n_full > 0) load_stage(0, m_begin);
 #pragma unroll 1
-  for (; m0 + step < m_end; m0 += 2 * step) {
-    load_stage(1, m0 + step);
+  for (long long sidx = 0; sidx < n_full; sidx += 2) {
+    const long long m0 = m_begin + sidx * step;
+    if (sidx + 1 < n_full) load_stage(1, m0 + step);
     __builtin_amdgcn_sched_barrier(0);
     mma_stage(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (m0 + 2 * step < m_end) load_stage(0, m0 + 2 * step);
+    if (sidx + 2 < n_full) load_stage(0, m0 + 2 * step);
     __builtin_amdgcn_sched_barrier(0);
-    mma_stage(1);
+    if (sidx + 1 < n_full) mma_stage(1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (m0 < m_end) mma_stage(0);
+  if (m_begin + n_full * step < m_end) {
+    load_stage_tail(0, m_begin + n_full * step);
+    mma_stage(0);
+  }
 
   // flush: C/D layout col = lane&31 (input column), row = (r&3) + 8*(r>>2) + 4*h (output row)
 #pragma unroll
