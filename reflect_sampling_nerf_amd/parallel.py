@@ -47,7 +47,12 @@ class FlatGradAllReduce:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
                 flat[self.total + i] = 1.0
             off += n
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if dist.get_backend(self.group) == "gloo" and flat.is_cuda:  # CPU rehearsal backend: stage through host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat[: self.total].mul_(1.0 / world)
         off = 0
         for i, (p, n) in enumerate(zip(self.params, self.sizes)):
