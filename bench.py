@@ -29,6 +29,7 @@ if REPO not in sys.path:
 
 FLOP_PER_SAMPLE = 1_230_592  # 2 x 615,296 MAC at W=256, L=8
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
 
 
 def parse():
@@ -44,6 +45,9 @@ def parse():
                     help="level = BASELINE configs[1] (default); get_outputs = full eval get_outputs "
                          "(coarse+fine+reflect); train = BASELINE configs[2]: full training step (forward, loss, "
                          "backward, gradient all-reduce, RAdam) with 64 coarse + 128 fine + reflect 64+64 samples")
+    ap.add_argument("--mma", default="f32", choices=["f32", "bf16x6", "bf16x3"],
+                    help="matrix-core arithmetic of the eval field kernel: f32 = exact fp32 MFMA (default); bf16x6 = "
+                         "fp32 emulation by 3-way bf16 splits (fp32-equivalent results); bf16x3 = reduced precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -133,6 +137,7 @@ def main():
     if args.workload == "train":
         model.train()
     fld = model.field
+    fld.set_mma_mode(args.mma)
     o, d, pa = synthetic_rays(R, seed=rank)  # each rank renders its own rays
     o, d, pa = o.to(dev), d.to(dev), pa.reshape(R).to(dev)
     nears = torch.full((R,), 2.0, device=dev)
@@ -188,6 +193,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.workload == "level" and args.mma == "f32" and world == 1:
+        # informational: the same workload with the fp32-emulating split-bf16 matrix-core mode (results agree with
+        # the exact-fp32 path to ~2e-7, tests/test_gpu_parity.py); `value` above stays the exact-fp32 number
+        alt = {}
+        for mode in ("bf16x6",):
+            fld.set_mma_mode(mode)
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            alt[mode] = {"value": R * args.steps / dt, "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3,
+                         "note": "fp32 emulation: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate"}
+        fld.set_mma_mode("f32")
+        state["alt"] = alt
     if args.workload != "level":
         with torch.no_grad():
             model.eval()
@@ -206,7 +229,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"f32": "f32", "bf16x6": "f32 (emulated: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate)",
+                      "bf16x3": "bf16x3 (2-way bf16 split, f32 accumulate; reduced precision)"}[args.mma],
             "data": "synthetic",
             "config": {
                 "workload": ("BASELINE configs[1]: %d rays x %d samples, %d-layer %d-wide MLP, fp32, fused forward + "
@@ -237,19 +261,26 @@ def main():
                         traffic = json.load(fh).get("hbm_traffic_bytes_per_launch")
                 except (OSError, IndexError, ValueError):
                     pass
+                # f32: algorithmic FLOP against the fp32-MFMA peak.  Split modes issue 6 (3) bf16 MFMA FLOP per
+                # algorithmic FLOP: priced as issued bf16 FLOP against the bf16 dense peak.
+                mult = {"f32": 1, "bf16x6": 6, "bf16x3": 3}[args.mma]
+                peak = FP32_MFMA_PEAK_TFLOPS if args.mma == "f32" else BF16_MFMA_PEAK_TFLOPS
                 line["roofline"] = {
-                    "kernel": "rsn_field_kernel<8>",
+                    "kernel": "rsn_field_kernel<8,false,%d>" % {"f32": 0, "bf16x6": 1, "bf16x3": 2}[args.mma],
                     "bound": "mfma",
-                    "achieved": achieved,
-                    "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "achieved": achieved * mult,
+                    "algorithmic_tflops": achieved,
+                    "peak": peak,
                     "unit": "TFLOP/s",
-                    "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "frac": achieved * mult / peak,
                     "traffic": traffic,
                     "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), PMC passes "
                                     "of tools/profile_round.sh, latest profiles/*_summary.json",
                     "kernel_ms": kms,
                     "algorithmic_flop_per_launch": flop,
                 }
+        if "alt" in state:
+            line["alt_mma_modes"] = state["alt"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

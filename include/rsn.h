@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 3
+#define RSN_ABI_VERSION 4
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -57,7 +57,16 @@ typedef struct rsn_field_desc {
   int32_t mid_width;    /* head_mlp_layer_width: 128 */
   float density_bias;   /* 0.5 */
   float freqs[RSN_NUM_FREQS];
+  int32_t mma_mode;     /* arithmetic of the dense GEMMs in the eval field kernel (rsn_mma_mode) */
 } rsn_field_desc;
+
+/* How the field kernel multiplies fp32 operands on the matrix cores:
+ *   RSN_MMA_F32     v_mfma_f32_32x32x2_f32: exact fp32 products (157 TFLOP/s peak);
+ *   RSN_MMA_BF16X6  fp32 emulation: both operands split exactly into 3 bf16 (8+8+8 mantissa bits), the 6 leading
+ *                   cross products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-24
+ *                   relative): fp32-equivalent results at 6/16 of the fp32-MFMA cost;
+ *   RSN_MMA_BF16X3  2-way split, 3 products (~2^-16 relative): reduced precision, opt-in only. */
+typedef enum rsn_mma_mode { RSN_MMA_F32 = 0, RSN_MMA_BF16X6 = 1, RSN_MMA_BF16X3 = 2 } rsn_mma_mode;
 
 /* Parameters in torch.nn.Linear layout: weight [out,in] row-major, bias [out]; names follow the
  * reference Field's state_dict (reflect_sampling_nerf_field.py:54-86).  field_output_low (:67) is

@@ -9,11 +9,12 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 3
+RSN_ABI_VERSION = 4
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
 RSN_SPACING_RECIPROCAL = 1
+RSN_MMA_F32, RSN_MMA_BF16X6, RSN_MMA_BF16X3 = 0, 1, 2
 
 _fp = C.c_void_p  # device float*
 
@@ -26,6 +27,7 @@ class FieldDesc(C.Structure):
         ("mid_width", C.c_int32),
         ("density_bias", C.c_float),
         ("freqs", C.c_float * RSN_NUM_FREQS),
+        ("mma_mode", C.c_int32),
     ]
 
 

@@ -10,6 +10,9 @@
 #define RSN_K_SH_PAD 40    // 34 SH inputs padded to 5 K-iterations of 8
 #define RSN_ENC_ITS (RSN_K_ENC_PAD / 8)
 #define RSN_SH_ITS (RSN_K_SH_PAD / 8)
+#define RSN_ENC_K16 7      // encoded inputs in K=16 steps (112 >= 104)
+#define RSN_SH_K16 3       // SH inputs in K=16 steps (48 >= 40)
+#define RSN_AUX_ITS 6      // LDS K-iterations reserved for the SH inputs (even, for the K=16 steps)
 
 void rsn_set_error(const char* fmt, ...);
 
@@ -52,6 +55,10 @@ struct RsnPackedLayout {
   size_t wT_mid_x;                    // (bottleneck part of mlp_mid)^T: rows W, K = mid_width
   size_t wT_rgb;                      // (RGB head)^T: rows mid_width, K = 32 (k = 4..6 live)
   size_t v_density;                   // density head weight row [W] (seed of the analytic-normal sweep)
+  // split-bf16 copies of the forward segments (RSN_MMA_BF16X6 / X3): [k16][nb][split(3)][lane][8 bf16];
+  // offsets in floats like everything else (one (k16, nb, split) chunk = 1 KiB = 256 floats)
+  size_t h_x[RSN_MAX_TRUNK_LAYERS];
+  size_t h_enc0, h_enc_skip, h_bh, h_mid_sh, h_mid_x, h_rgb;
   size_t total;                       // floats
 };
 

@@ -161,10 +161,10 @@ __device__ __forceinline__ void sh34_attenuated(float x, float y, float z, float
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int NB, bool TRAIN>
+template <int NB, bool TRAIN, int MODE>
 __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
-  constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;  // >= 13 (encoding) and >= 16 (mid hidden)
-  constexpr int WAVE_F4 = (XITS + RSN_SH_ITS) * 64;
+  constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;  // >= 14 (encoding, K=16 steps) and >= 16 (mid hidden)
+  constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
   constexpr int W = NB * 32;
   __shared__ float4 smem[4 * WAVE_F4];
 
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       float4 raw = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (h == 0) raw = make_float4(mc[0], mc[1], mc[2], 0.0f);
       X[12 * 64] = raw;
+      if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // K=16 steps read iteration 13 (zero weights)
     }
     // this lane's 52 encoded inputs, re-used by the skip layer.  Held as vector-typed SSA values (not an
     // indexable array) so that they stay in the unified VGPR/AGPR file instead of scratch memory.
@@ -275,12 +276,12 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     {
       f32x16 acc[NB];
       init_acc<NB>(acc, pk + a.L.b[0], h);
-      gemm<NB>(acc, pk + a.L.w_enc0, X, RSN_ENC_ITS, lane);
+      gemm_mode<MODE, NB>(acc, pk + a.L.w_enc0, pk + a.L.h_enc0, X, RSN_ENC_ITS, lane);
       store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + pc * W : nullptr, h);
 #pragma unroll 1
       for (int l = 1; l < a.num_layers; ++l) {
         init_acc<NB>(acc, pk + a.L.b[l], h);
-        gemm<NB>(acc, pk + a.L.w_x[l], X, NB * 4, lane);
+        gemm_mode<MODE, NB>(acc, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, lane);
         if (l == a.skip_layer) {
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
@@ -289,7 +290,8 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
             X[(8 + it) * 64] = make_float4(st2[4 * it], st2[4 * it + 1], st2[4 * it + 2], st2[4 * it + 3]);
           }
           X[12 * 64] = st3;
-          gemm<NB>(acc, pk + a.L.w_enc_skip, X, RSN_ENC_ITS, lane);
+          if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          gemm_mode<MODE, NB>(acc, pk + a.L.w_enc_skip, pk + a.L.h_enc_skip, X, RSN_ENC_ITS, lane);
         }
         // ReLU between layers and out_activation=ReLU
         store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + l * a.act_stride + pc * W : nullptr, h);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     {
       f32x16 acc[NB + 1];
       init_acc<NB + 1>(acc, pk + a.L.b_bh, h);
-      gemm<NB + 1>(acc, pk + a.L.w_bh, X, NB * 4, lane);
+      gemm_mode<MODE, NB + 1>(acc, pk + a.L.w_bh, pk + a.L.h_bh, X, NB * 4, lane);
       const float r0 = acc[NB][0], r1 = acc[NB][1], r2 = acc[NB][2], r3 = acc[NB][3];
       const float r4 = acc[NB][4], r5 = acc[NB][5], r6 = acc[NB][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
@@ -364,6 +366,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           vals[s] = (u < 17) ? (h ? sh[17 + u] : sh[u]) : 0.0f;
         }
         AUX[it * 64] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+        if (MODE != 0 && it == 0) AUX[5 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (TRAIN && a.saved.sh && valid)
           *reinterpret_cast<float4*>(a.saved.sh + pc * RSN_K_SH_PAD + it * 8 + 4 * h) =
               make_float4(vals[0], vals[1], vals[2], vals[3]);
@@ -374,14 +377,14 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     {
       f32x16 accm[4];
       init_acc<4>(accm, pk + a.L.b_mid, h);
-      gemm<4>(accm, pk + a.L.w_mid_sh, AUX, RSN_SH_ITS, lane);
-      gemm<4>(accm, pk + a.L.w_mid_x, X, NB * 4, lane);
+      gemm_mode<MODE, 4>(accm, pk + a.L.w_mid_sh, pk + a.L.h_mid_sh, AUX, RSN_SH_ITS, lane);
+      gemm_mode<MODE, 4>(accm, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, lane);
       store_act<4, 4, true>(accm, X, (TRAIN && a.saved.hid && valid) ? a.saved.hid + pc * 128 : nullptr, h);
     }
     {
       f32x16 accr[1];
       init_acc<1>(accr, pk + a.L.b_rgb, h);
-      gemm<1>(accr, pk + a.L.w_rgb, X, 16, lane);
+      gemm_mode<MODE, 1>(accr, pk + a.L.w_rgb, pk + a.L.h_rgb, X, 16, lane);
       if (h == 1 && valid) {
         const float m0 = sigmoid_f(accr[0][0]);
         const float m1 = sigmoid_f(accr[0][1]);
@@ -489,21 +492,24 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool train = a.saved.act != nullptr || a.saved.enc != nullptr || a.saved.heads != nullptr;
   a.act_stride = n_points * (long long)d->width;
+  const int mode = train ? 0 : d->mma_mode;  // the training kernels (saved activations, sweeps) are fp32-MFMA only
+#define RSN_LAUNCH(NBV)                                                                                          \
+  do {                                                                                                           \
+    if (train) hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);   \
+    else if (mode == RSN_MMA_BF16X6)                                                                            \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
+    else if (mode == RSN_MMA_BF16X3)                                                                            \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
+    else                                                                                                         \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
+  } while (0)
   switch (d->width) {
-    case 256:
-      if (train) hipLaunchKernelGGL((rsn_field_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((rsn_field_kernel<8, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
-      break;
-    case 128:
-      if (train) hipLaunchKernelGGL((rsn_field_kernel<4, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((rsn_field_kernel<4, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
-      break;
-    case 64:
-      if (train) hipLaunchKernelGGL((rsn_field_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((rsn_field_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
-      break;
+    case 256: RSN_LAUNCH(8); break;
+    case 128: RSN_LAUNCH(4); break;
+    case 64: RSN_LAUNCH(2); break;
     default: RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "width=%d unsupported", d->width);
   }
+#undef RSN_LAUNCH
   RSN_HIP(hipGetLastError());
   return RSN_OK;
 }

@@ -105,7 +105,7 @@ __device__ __forceinline__ void normalize_bwd(const float x[3], const float gy[3
 template <int NB>
 __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
   constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;
-  constexpr int WAVE_F4 = (XITS + RSN_SH_ITS) * 64;
+  constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
   constexpr int W = NB * 32;
   __shared__ float4 smem[4 * WAVE_F4];
 

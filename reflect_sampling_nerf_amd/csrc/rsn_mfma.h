@@ -84,6 +84,103 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[NBO], const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 K loop (RSN_MMA_BF16X6 / X3): the same GEMM on v_mfma_f32_32x32x16_bf16.
+// One K=16 step consumes the lane's two float4's of LDS iterations 2kk, 2kk+1 (same lane-local activations as
+// the fp32 loop).  The 8 fp32 activations are split exactly into bf16 triples in registers; the weights arrive
+// pre-split ([k16][nb][split][lane][8 bf16], rsn_pack.hip).  NSPLIT = 3: products w1x1, w1x2, w2x1, w1x3, w2x2,
+// w3x1 (dropped terms <= 2^-24 relative);  NSPLIT = 2: w1x1, w1x2, w2x1.
+// Weight fragments are double-buffered at half-step granularity (half of the output blocks) to fit the VGPR budget.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct BSplit {
+  bf16x8 s1, s2, s3;
+};
+
+template <int NSPLIT>
+__device__ __forceinline__ BSplit split8(const float4 lo, const float4 hi) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  BSplit o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 b1 = (__bf16)x[e];
+    const float r1 = x[e] - (float)b1;
+    const __bf16 b2 = (__bf16)r1;
+    o.s1[e] = b1;
+    o.s2[e] = b2;
+    if (NSPLIT == 3) {
+      const float r2 = r1 - (float)b2;
+      o.s3[e] = (__bf16)r2;
+    } else {
+      o.s3[e] = (__bf16)0.0f;
+    }
+  }
+  return o;
+}
+
+template <int NH, int NSPLIT>
+__device__ __forceinline__ void load_w16(bf16x8 (&w)[NH][3], const bf16x8* __restrict__ wp, int kk, int nbo, int nb0) {
+#pragma unroll
+  for (int t = 0; t < NH; ++t)
+#pragma unroll
+    for (int sp = 0; sp < NSPLIT; ++sp) w[t][sp] = wp[((kk * nbo + nb0 + t) * 3 + sp) * 64];
+}
+
+template <int NBO, int NH, int NB0, int NSPLIT>
+__device__ __forceinline__ void mma16(f32x16 (&acc)[NBO], const bf16x8 (&w)[NH][3], const BSplit& b) {
+#pragma unroll
+  for (int t = 0; t < NH; ++t) {
+    f32x16 c = acc[NB0 + t];
+    if (NSPLIT == 3) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][2], b.s1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][1], b.s2, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][0], b.s3, c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][1], b.s1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][0], b.s2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][0], b.s1, c, 0, 0, 0);
+    acc[NB0 + t] = c;
+  }
+}
+
+template <int NBO, int NSPLIT>
+__device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl,
+                                          int n_k16, int lane) {
+  constexpr int H0 = (NBO + 1) / 2, H1 = NBO - H0;
+  const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(wseg) + lane;
+  bf16x8 wa[H0][3], wb[H1 > 0 ? H1 : 1][3];
+  load_w16<H0, NSPLIT>(wa, wp, 0, NBO, 0);
+  BSplit bc = split8<NSPLIT>(xl[0], xl[64]);
+#pragma unroll 1
+  for (int kk = 0; kk < n_k16; ++kk) {
+    if (H1 > 0) load_w16<(H1 > 0 ? H1 : 1), NSPLIT>(wb, wp, kk, NBO, H0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma16<NBO, H0, 0, NSPLIT>(acc, wa, bc);
+    __builtin_amdgcn_sched_barrier(0);
+    BSplit bn = bc;
+    if (kk + 1 < n_k16) {
+      load_w16<H0, NSPLIT>(wa, wp, kk + 1, NBO, 0);
+      bn = split8<NSPLIT>(xl[(2 * kk + 2) * 64], xl[(2 * kk + 3) * 64]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (H1 > 0) mma16<NBO, (H1 > 0 ? H1 : 1), (H1 > 0 ? H0 : 0), NSPLIT>(acc, wb, bc);
+    __builtin_amdgcn_sched_barrier(0);
+    bc = bn;
+  }
+}
+
+// dispatch on the MMA mode: MODE 0 = fp32 MFMA over n_it K-iterations of 8, else split-bf16 over ceil(n_it/2) K=16 steps
+template <int MODE, int NBO>
+__device__ __forceinline__ void gemm_mode(f32x16 (&acc)[NBO], const float* __restrict__ w32, const float* __restrict__ w16,
+                                          const float4* xl, int n_it, int lane) {
+  if (MODE == 0) {
+    gemm<NBO>(acc, w32, xl, n_it, lane);
+  } else {
+    gemm_bf16<NBO, (MODE == 1 ? 3 : 2)>(acc, w16, xl, (n_it + 1) / 2, lane);
+  }
+}
+
 template <int NBO>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
 #pragma unroll

@@ -107,6 +107,15 @@ class ReflectSamplingNeRFNerfField(Field):
         self._packed: Optional[Tensor] = None
         self._packed_key = None
         self._desc: Optional[FieldDesc] = None
+        self.mma_mode = _abi.RSN_MMA_F32
+
+    MMA_MODES = {"f32": _abi.RSN_MMA_F32, "bf16x6": _abi.RSN_MMA_BF16X6, "bf16x3": _abi.RSN_MMA_BF16X3}
+
+    def set_mma_mode(self, mode: str) -> None:
+        """Arithmetic of the dense GEMMs in the eval field kernel: "f32" (exact fp32 MFMA), "bf16x6" (fp32
+        emulation by 3-way bf16 splits, fp32-equivalent) or "bf16x3" (2-way split, reduced precision, opt-in)."""
+        self.mma_mode = self.MMA_MODES[mode]
+        self._desc = None
 
     # ------------------------------------------------------------------ C-ABI plumbing
     @property
@@ -123,6 +132,7 @@ class ReflectSamplingNeRFNerfField(Field):
             d.skip_layer = live[0] if live else -1
             d.mid_width = self.mlp_mid.layer_width
             d.density_bias = float(self.density_bias)
+            d.mma_mode = int(self.mma_mode)
             pe = self.position_encoding
             freqs = 2 ** torch.linspace(float(pe.min_freq), float(pe.max_freq), int(pe.num_frequencies))
             for i in range(16):

@@ -455,3 +455,49 @@ def test_training_trajectory_and_psnr_match_oracle(dev):
     assert abs(res["loss_last"][0] - res["loss_last"][1]) <= 1e-3 * abs(res["loss_last"][0])
     assert abs(res["psnr_delta_db"]) <= 0.1
     assert res["psnr_hip_vs_oracle_render"] >= 50.0
+
+
+# ---------------------------------------------------------------------------------------------- split-bf16 MMA modes
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 1e-4), ("bf16x3", 2e-3)])
+@pytest.mark.parametrize("layers,width", [(8, 256), (4, 128), (8, 64)])
+def test_field_level_split_bf16_modes(dev, mode, tol, layers, width):
+    """RSN_MMA_BF16X6 (fp32 emulation, must meet the fp32 tolerance) and RSN_MMA_BF16X3 (opt-in reduced precision)."""
+    R, S = 19, 24
+    fld, P, fs = make_field(layers, width, dev, seed=layers * 10 + width, bias_shift=1.0)
+    fld.set_mma_mode(mode)
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=3)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    _, eb = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S, None)
+    with torch.no_grad():
+        ref = cpu_ref.field_level(P, fs, o, d, pa, eb, training=False, want_normals=False)
+    lv = fld.evaluate_frustums(o.to(dev), d.to(dev), pa.reshape(R).to(dev), eb.contiguous().to(dev))
+    torch.cuda.synchronize()
+    assert max_abs(lv["sigma"].cpu(), ref["sigma"][..., 0]) <= tol
+    assert max_abs(lv["color"].cpu(), ref["color"]) <= tol
+    assert max_abs(lv["diff"].cpu(), ref["diff"]) <= tol
+    assert max_abs(lv["pred_normals"].cpu(), ref["pred_normals"]) <= max(tol, TOL_UNIT) * (10 if mode == "bf16x3" else 1)
+
+
+def test_get_outputs_bf16x6_meets_fp32_tolerance(dev):
+    torch.manual_seed(12)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=32, num_importance_samples=32,
+                                            num_reflect_coarse_samples=16, num_reflect_importance_samples=16,
+                                            base_mlp_num_layers=8, base_mlp_layer_width=256)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 2.0
+    P = {k: v.detach().clone() for k, v in model.field.state_dict().items()}
+    model.to(dev).eval()
+    model.field.set_mma_mode("bf16x6")
+    R = 70
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=62)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev), nears=nears.to(dev),
+                       fars=fars.to(dev))
+    out = model(rb)
+    with torch.no_grad():
+        ref = cpu_ref.get_outputs(P, cpu_ref.FieldSpec(), cpu_ref.ModelSpec(32, 32, 16, 16), o, d, pa, nears, fars)
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "accumulation_coarse",
+              "accumulation_fine", "weights_fine", "diff", "tint", "roughness"):
+        assert max_abs(out[k].cpu(), ref[k]) <= TOL, k
+    assert torch.equal(out["mask"].cpu(), ref["mask"])
