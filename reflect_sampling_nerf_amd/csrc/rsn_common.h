@@ -59,6 +59,8 @@ struct RsnPackedLayout {
   // offsets in floats like everything else (one (k16, nb, split) chunk = 1 KiB = 256 floats)
   size_t h_x[RSN_MAX_TRUNK_LAYERS];
   size_t h_enc0, h_enc_skip, h_bh, h_mid_sh, h_mid_x, h_rgb;
+  size_t hT_x[RSN_MAX_TRUNK_LAYERS];  // split-bf16 copies of the transposed segments (training sweeps)
+  size_t hT_enc0, hT_enc_skip, hT_bh, hT_mid_x, hT_rgb;
   size_t total;                       // floats
 };
 

@@ -424,13 +424,13 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       zero_acc<4>(eacc);
 #pragma unroll 1
       for (int l = a.num_layers - 1; l >= 1; --l) {
-        if (l == a.skip_layer) gemm<4>(eacc, pk + a.L.wT_enc_skip, X, NB * 4, lane);
+        if (l == a.skip_layer) gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, lane);
         f32x16 acc[NB];
         zero_acc<NB>(acc);
-        gemm<NB>(acc, pk + a.L.wT_x[l], X, NB * 4, lane);
+        gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, lane);
         store_masked<NB>(acc, X, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
       }
-      gemm<4>(eacc, pk + a.L.wT_enc0, X, NB * 4, lane);
+      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, lane);
       store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
       float nrm[3];
 #pragma unroll 1
@@ -492,10 +492,13 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool train = a.saved.act != nullptr || a.saved.enc != nullptr || a.saved.heads != nullptr;
   a.act_stride = n_points * (long long)d->width;
-  const int mode = train ? 0 : d->mma_mode;  // the training kernels (saved activations, sweeps) are fp32-MFMA only
+  const int mode = d->mma_mode;
 #define RSN_LAUNCH(NBV)                                                                                          \
   do {                                                                                                           \
-    if (train) hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);   \
+    if (train && mode == RSN_MMA_BF16X6)                                                                        \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
+    else if (train)  /* BF16X3 is an eval-only opt-in: training falls back to exact fp32 */                      \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
     else if (mode == RSN_MMA_BF16X6)                                                                            \
       hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
     else if (mode == RSN_MMA_BF16X3)                                                                            \

@@ -7,8 +7,8 @@
 // next one.  ReLU masks come from the post-ReLU activations the training forward saved (x > 0).
 //
 // What leaves the kernel are the PRE-ACTIVATION gradients of every linear layer, row-major [N, out_features]:
-// the weight gradients dW = dY^T X (contraction over all N samples) are plain, large GEMMs and are taken by the
-// host with the BLAS library (hipBLASLt/rocBLAS through torch.mm), the bias gradients by rsn_colsum.
+// the weight gradients dW = dY^T X (contraction over all N samples) and the bias gradients are taken by
+// rsn_weight_grad (rsn_wgrad.hip).
 //
 // Autograd semantics restated (reference: reflect_sampling_nerf_model.py:142-344, field.py:122-207):
 //   colour = diff + tint * mid          -> d diff = g, d tint = g*mid, d mid = g*tint
@@ -102,7 +102,7 @@ __device__ __forceinline__ void normalize_bwd(const float x[3], const float gy[3
   gx[2] = (gy[2] - y2 * dot) / len;
 }
 
-template <int NB>
+template <int NB, int MODE>
 __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
   constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;
   constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
@@ -163,14 +163,14 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     {
       f32x16 acc[4];
       zero_acc<4>(acc);
-      gemm<4>(acc, pk + a.L.wT_rgb, X, 4, lane);
+      gemm_mode<MODE, 4>(acc, pk + a.L.wT_rgb, pk + a.L.hT_rgb, X, 4, lane);
       store_masked<4>(acc, X, a.saved.hid + pc * 128, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm<NB>(acc, pk + a.L.wT_mid_x, X, 16, lane);
+      gemm_mode<MODE, NB>(acc, pk + a.L.wT_mid_x, pk + a.L.hT_mid_x, X, 16, lane);
       store_act<NB, NB, false>(acc, X, (valid && a.gout.d_bott) ? a.gout.d_bott + pc * W : nullptr, h);
     }
     // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
       }
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm<NB>(acc, pk + a.L.wT_bh, X, NB * 4 + 4, lane);
+      gemm_mode<MODE, NB>(acc, pk + a.L.wT_bh, pk + a.L.hT_bh, X, NB * 4 + 4, lane);
       const int l = a.num_layers - 1;
       store_masked<NB>(acc, X, a.saved.act + (long long)l * a.act_stride + pc * W, h,
                        valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
@@ -235,16 +235,17 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     zero_acc<4>(eacc);
 #pragma unroll 1
     for (int l = a.num_layers - 1; l >= 1; --l) {
-      if (a.need_input_grad && l == a.skip_layer) gemm<4>(eacc, pk + a.L.wT_enc_skip, X, NB * 4, lane);
+      if (a.need_input_grad && l == a.skip_layer)
+        gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, lane);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm<NB>(acc, pk + a.L.wT_x[l], X, NB * 4, lane);
+      gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, lane);
       store_masked<NB>(acc, X, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h,
                        valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
     if (a.need_input_grad) {
-      gemm<4>(eacc, pk + a.L.wT_enc0, X, NB * 4, lane);
+      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, lane);
       store_act<4, 4, false>(eacc, X);  // d loss / d encoded input, slot order
       const float* encp = a.saved.enc + pc * RSN_K_ENC_PAD;
       float dvar[3];
@@ -314,12 +315,19 @@ static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
   }
   const long long grid = n_tiles < (long long)cached_cus ? n_tiles : (long long)cached_cus;
   hipStream_t st = (hipStream_t)stream;
+  const bool x6 = d->mma_mode == RSN_MMA_BF16X6;  // fp32-emulating split-bf16 sweeps (opt-in); else exact fp32
+#define RSN_LAUNCH_BWD(NBV)                                                                                  \
+  do {                                                                                                       \
+    if (x6) hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
+    else hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);       \
+  } while (0)
   switch (d->width) {
-    case 256: hipLaunchKernelGGL(rsn_field_bwd_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
-    case 128: hipLaunchKernelGGL(rsn_field_bwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
-    case 64: hipLaunchKernelGGL(rsn_field_bwd_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    case 256: RSN_LAUNCH_BWD(8); break;
+    case 128: RSN_LAUNCH_BWD(4); break;
+    case 64: RSN_LAUNCH_BWD(2); break;
     default: RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "width=%d unsupported", d->width);
   }
+#undef RSN_LAUNCH_BWD
   RSN_HIP(hipGetLastError());
   return RSN_OK;
 }

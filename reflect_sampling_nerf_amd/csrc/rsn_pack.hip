@@ -112,6 +112,21 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   off += (size_t)(L->nb * 2) * L->nbm * 3 * blk;
   L->h_rgb = off;
   off += (size_t)(L->nbm * 2) * 1 * 3 * blk;
+  for (int l = 1; l < d->num_layers; ++l) {
+    L->hT_x[l] = off;
+    off += hx_seg;
+  }
+  const size_t hencT_seg = (size_t)(L->nb * 2) * 4 * 3 * blk;
+  L->hT_enc0 = off;
+  off += hencT_seg;
+  L->hT_enc_skip = off;
+  off += (d->skip_layer >= 1) ? hencT_seg : 0;
+  L->hT_bh = off;
+  off += (size_t)(L->nb * 2 + 2) * L->nb * 3 * blk;
+  L->hT_mid_x = off;
+  off += (size_t)(L->nbm * 2) * L->nb * 3 * blk;
+  L->hT_rgb = off;
+  off += (size_t)2 * L->nbm * 3 * blk;
   L->total = off;
   return RSN_OK;
 }
@@ -168,31 +183,29 @@ __global__ void rsn_pack_kernel(const PackJob job) {
   job.dst[e] = v;
 }
 
-// split-bf16 copy of a (non-transposed) segment: element (kk, nb, lane=(i,h), e) is the fp32 weight
-// W[row(nb*32+i)][col((2kk + (e>>2))*8 + 4h + (e&3))] split EXACTLY into three bf16 (v = b1 + b2 + b3 up to 2^-24):
-// the K=16 MFMA step kk consumes the same lane-local activations as the two fp32 K-iterations 2kk, 2kk+1.
-__global__ void rsn_pack_bf16_kernel(const PackJob job) {
+// split-bf16 copy of an already packed fp32 segment [it][nb][lane][4] -> [k16][nb][split(3)][lane][8 bf16]:
+// element e of K=16 step kk is the fp32 value of K-iteration 2kk + (e>>2), component e&3 (zero beyond n_it), split
+// EXACTLY into three bf16 (v = b1 + b2 + b3 up to 2^-24): the K=16 MFMA step consumes the same lane-local
+// activations as the two fp32 K-iterations it replaces.  Works for forward and transposed segments alike.
+__global__ void rsn_pack_split_kernel(const float* __restrict__ src, int n_it, int nbo, float* dstf) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n_k16 = job.n_it / 2;
-  if (e >= n_k16 * job.nbo * 512) return;
+  const int n_k16 = (n_it + 1) / 2;
+  if (e >= n_k16 * nbo * 512) return;
   const int ee = e & 7;
   const int lane = (e >> 3) & 63;
   const int chunk = e >> 9;
-  const int nb = chunk % job.nbo;
-  const int kk = chunk / job.nbo;
-  const int n = nb * 32 + (lane & 31);
-  const int k = (2 * kk + (ee >> 2)) * 8 + 4 * (lane >> 5) + (ee & 3);
-  const int rs = job.row_src[n];
-  const int c = (k < PACK_MAX_COLS) ? job.col[k] : -1;
+  const int nb = chunk % nbo;
+  const int kk = chunk / nbo;
+  const int it = 2 * kk + (ee >> 2);
   float v = 0.0f;
-  if (rs >= 0 && c >= 0) v = job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
+  if (it < n_it) v = src[((size_t)(it * nbo + nb) * 64 + lane) * 4 + (ee & 3)];
   const __bf16 b1 = (__bf16)v;
   const float r1 = v - (float)b1;
   const __bf16 b2 = (__bf16)r1;
   const float r2 = r1 - (float)b2;
   const __bf16 b3 = (__bf16)r2;
-  __bf16* dst = reinterpret_cast<__bf16*>(job.dst);
-  const size_t base = (size_t)(kk * job.nbo + nb) * 3;
+  __bf16* dst = reinterpret_cast<__bf16*>(dstf);
+  const size_t base = (size_t)(kk * nbo + nb) * 3;
   dst[((base + 0) * 64 + lane) * 8 + ee] = b1;
   dst[((base + 1) * 64 + lane) * 8 + ee] = b2;
   dst[((base + 2) * 64 + lane) * 8 + ee] = b3;
@@ -252,10 +265,11 @@ void cols_sh(PackJob& j) {
   }
 }
 
-int launch_bf16(const PackJob& j, hipStream_t st) {  // j.n_it = 2 * n_k16 (even), forward (non-transposed) jobs only
-  const int total = (j.n_it / 2) * j.nbo * 512;
+int split_seg(const float* src, int n_it, int nbo, float* dst, hipStream_t st) {
+  const int total = ((n_it + 1) / 2) * nbo * 512;
   const int threads = 256;
-  hipLaunchKernelGGL(rsn_pack_bf16_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, j);
+  hipLaunchKernelGGL(rsn_pack_split_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, src, n_it, nbo,
+                     dst);
   RSN_HIP(hipGetLastError());
   return RSN_OK;
 }
@@ -296,23 +310,17 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; j.dst = packed + L.w_enc0; j.n_it = RSN_ENC_ITS; j.nbo = NB;
       rows_natural(j, W); cols_encoding(j);
       if ((rc = launch(j, st)) != RSN_OK) return rc;
-      j.dst = packed + L.h_enc0; j.n_it = 2 * RSN_ENC_K16;
-      if ((rc = launch_bf16(j, st)) != RSN_OK) return rc;
     } else {
       clear_job(j);
       j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; j.dst = packed + L.w_x[l]; j.n_it = NB * 4; j.nbo = NB;
       rows_natural(j, W);
       cols_natural(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0);  // cat([encoding, x]): x columns come second
       if ((rc = launch(j, st)) != RSN_OK) return rc;
-      j.dst = packed + L.h_x[l];
-      if ((rc = launch_bf16(j, st)) != RSN_OK) return rc;
       if (l == d->skip_layer) {
         clear_job(j);
         j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; j.dst = packed + L.w_enc_skip; j.n_it = RSN_ENC_ITS; j.nbo = NB;
         rows_natural(j, W); cols_encoding(j);
         if ((rc = launch(j, st)) != RSN_OK) return rc;
-        j.dst = packed + L.h_enc_skip; j.n_it = 2 * RSN_ENC_K16;
-        if ((rc = launch_bf16(j, st)) != RSN_OK) return rc;
       }
     }
     clear_job(j);
@@ -344,8 +352,6 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   j.dst = packed + L.w_bh; j.n_it = NB * 4; j.nbo = NB + 1;
   rows_natural(j, W); heads_rows(j, W); cols_natural(j, W, 0);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
-  j.dst = packed + L.h_bh;
-  if ((rc = launch_bf16(j, st)) != RSN_OK) return rc;
   clear_job(j);
   j.is_bias = 1; j.n_rows = W + 32; j.dst = packed + L.b_bh;
   j.src[0] = p->bottleneck_b; j.src[1] = p->density_b; j.src[2] = p->normals_b; j.src[3] = p->diff_b;
@@ -358,14 +364,10 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; j.dst = packed + L.w_mid_sh; j.n_it = RSN_SH_ITS; j.nbo = NBM;
   rows_natural(j, d->mid_width); cols_sh(j);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
-  j.dst = packed + L.h_mid_sh; j.n_it = 2 * RSN_SH_K16;
-  if ((rc = launch_bf16(j, st)) != RSN_OK) return rc;
   clear_job(j);
   j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; j.dst = packed + L.w_mid_x; j.n_it = NB * 4; j.nbo = NBM;
   rows_natural(j, d->mid_width); cols_natural(j, W, RSN_SH_DIM);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
-  j.dst = packed + L.h_mid_x;
-  if ((rc = launch_bf16(j, st)) != RSN_OK) return rc;
   clear_job(j);
   j.is_bias = 1; j.n_rows = d->mid_width; j.src[0] = p->mid_b; j.dst = packed + L.b_mid;
   rows_natural(j, d->mid_width);
@@ -377,8 +379,6 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   for (int c = 0; c < 3; ++c) { j.row_src[4 + c] = 0; j.row_idx[4 + c] = (int16_t)c; }
   cols_natural(j, d->mid_width, 0);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
-  j.dst = packed + L.h_rgb;
-  if ((rc = launch_bf16(j, st)) != RSN_OK) return rc;
   clear_job(j);
   j.is_bias = 1; j.n_rows = 32; j.src[0] = p->rgb_b; j.dst = packed + L.b_rgb;
   for (int c = 0; c < 3; ++c) { j.row_src[4 + c] = 0; j.row_idx[4 + c] = (int16_t)c; }
@@ -447,5 +447,24 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   j.is_bias = 1; j.n_rows = W; j.src[0] = p->density_w; j.dst = packed + L.v_density;
   rows_natural(j, W);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
+
+  // ---------------- split-bf16 copies (RSN_MMA_BF16X6 / X3) of every GEMM segment ----------------
+  if ((rc = split_seg(packed + L.w_enc0, RSN_ENC_ITS, NB, packed + L.h_enc0, st)) != RSN_OK) return rc;
+  for (int l = 1; l < d->num_layers; ++l) {
+    if ((rc = split_seg(packed + L.w_x[l], NB * 4, NB, packed + L.h_x[l], st)) != RSN_OK) return rc;
+    if ((rc = split_seg(packed + L.wT_x[l], NB * 4, NB, packed + L.hT_x[l], st)) != RSN_OK) return rc;
+  }
+  if (d->skip_layer >= 1) {
+    if ((rc = split_seg(packed + L.w_enc_skip, RSN_ENC_ITS, NB, packed + L.h_enc_skip, st)) != RSN_OK) return rc;
+    if ((rc = split_seg(packed + L.wT_enc_skip, NB * 4, 4, packed + L.hT_enc_skip, st)) != RSN_OK) return rc;
+  }
+  if ((rc = split_seg(packed + L.wT_enc0, NB * 4, 4, packed + L.hT_enc0, st)) != RSN_OK) return rc;
+  if ((rc = split_seg(packed + L.w_bh, NB * 4, NB + 1, packed + L.h_bh, st)) != RSN_OK) return rc;
+  if ((rc = split_seg(packed + L.wT_bh, NB * 4 + 4, NB, packed + L.hT_bh, st)) != RSN_OK) return rc;
+  if ((rc = split_seg(packed + L.w_mid_sh, RSN_SH_ITS, NBM, packed + L.h_mid_sh, st)) != RSN_OK) return rc;
+  if ((rc = split_seg(packed + L.w_mid_x, NB * 4, NBM, packed + L.h_mid_x, st)) != RSN_OK) return rc;
+  if ((rc = split_seg(packed + L.wT_mid_x, NBM * 4, NB, packed + L.hT_mid_x, st)) != RSN_OK) return rc;
+  if ((rc = split_seg(packed + L.w_rgb, NBM * 4, 1, packed + L.h_rgb, st)) != RSN_OK) return rc;
+  if ((rc = split_seg(packed + L.wT_rgb, 4, NBM, packed + L.hT_rgb, st)) != RSN_OK) return rc;
   return RSN_OK;
 }

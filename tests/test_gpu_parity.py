@@ -347,7 +347,8 @@ def _coarse_loss(out, tgt):
     (8, 128, (32, 24, 16, 12), 37, 1.5),
     (4, 64, (16, 16, 8, 8), 40, 2.0),
 ])
-def test_train_forward_backward_matches_oracle_autograd(dev, layers, width, samples, R, bias):
+@pytest.mark.parametrize("mma", ["f32", "bf16x6"])
+def test_train_forward_backward_matches_oracle_autograd(dev, layers, width, samples, R, bias, mma):
     """Training-mode get_outputs (stratified jitter, analytic normals) and its backward against autograd through the
     oracle, with the samplers' uniform draws shared.
 
@@ -367,6 +368,7 @@ def test_train_forward_backward_matches_oracle_autograd(dev, layers, width, samp
         model.field.field_output_density.net.bias += bias
     P = {k: v.detach().clone().requires_grad_(True) for k, v in model.field.state_dict().items()}
     model.to(dev).train()
+    model.field.set_mma_mode(mma)  # bf16x6: the fp32-emulating split-bf16 sweeps must meet the same bounds
     o, d, pa = cpu_ref.synthetic_rays(R, seed=seed + 50)
     nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
     fs, ms = cpu_ref.FieldSpec(num_layers=layers, width=width), cpu_ref.ModelSpec(*samples)
