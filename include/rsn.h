@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 4
+#define RSN_ABI_VERSION 5
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -208,6 +208,28 @@ int rsn_field_forward_inf(const rsn_field_desc* desc, const float* packed, int32
 int rsn_field_forward_gaussians(const rsn_field_desc* desc, const float* packed, int32_t n_points,
                                 const float* means, const float* cov_diag, const float* view_dirs,
                                 const rsn_field_outputs* out, float* embedding, void* stream);
+
+/* rsn_field_forward_embedding: the head getters of the granular Field API on a caller-supplied embedding [N,W]
+ * (post-ReLU trunk output, as returned by get_density): get_pred_normals, get_diff, get_tint, get_roughness
+ * (out->roughness = sigmoid, out->raw_density = density head), get_mid / get_low (out->color = diff + tint*mid
+ * is NOT what get_mid returns: the mid colour itself is written to out->color when out->diff and out->tint are
+ * NULL).  view_dirs NULL => SH inputs zeroed (get_low); roughness [N] NULL => softplus(roughness head)
+ * (reflect_sampling_nerf_field.py:139-186). */
+int rsn_field_forward_embedding(const rsn_field_desc* desc, const float* packed, int32_t n_points,
+                                const float* embedding, const float* view_dirs, const float* roughness,
+                                const rsn_field_outputs* out, void* stream);
+
+/* ---- granular geometry (Field.get_blob / contract / get_reflection) --------------------------------------
+ * rsn_gaussians: conical frustum -> Gaussian per sample (reflect_sampling_nerf_field.py:90-96 ->
+ * Frustums.get_gaussian_blob): per-sample origins/directions [N,3], pixel_area/starts/ends [N] ->
+ * mean [N,3], cov [N,3,3]. */
+int rsn_gaussians(int64_t n, const float* origins, const float* directions, const float* pixel_area,
+                  const float* starts, const float* ends, float* mean, float* cov, void* stream);
+/* rsn_contract: reflect_sampling_nerf_field.py:98-119: mean' and J cov J with the diagonal clamped >= 0. */
+int rsn_contract(int64_t n, const float* mean, const float* cov, float* mean_out, float* cov_out, void* stream);
+/* rsn_reflection: reflect_sampling_nerf_field.py:203-207: n_dot_d [N] and normalize(d - 2 (n.d) n) [N,3]. */
+int rsn_reflection(int64_t n, const float* directions, const float* normals, float* reflections, float* n_dot_d,
+                   void* stream);
 
 /* ---- compositing ------------------------------------------------------------------------------
  * rsn_composite: RaySamples.get_weights + RGB/Accumulation/Depth(median)/Normals/Semantic

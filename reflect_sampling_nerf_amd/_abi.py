@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 4
+RSN_ABI_VERSION = 5
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -114,6 +114,11 @@ _SIGNATURES = {
     "rsn_reflect_default_backward": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_reflect_combine_backward": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_field_forward_inf": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_field_forward_embedding": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp,
+                                              C.POINTER(FieldOutputs), C.c_void_p]),
+    "rsn_gaussians": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_contract": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_reflection": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_field_forward_gaussians": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp,
                                               C.POINTER(FieldOutputs), _fp, C.c_void_p]),
     "rsn_composite": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CompositeIO),

@@ -38,6 +38,8 @@ struct FieldArgs {
   const float* view_dirs;
   rsn_field_outputs out;
   float* embedding;
+  const float* emb_in;        // RSN_MODE_EMB: [N,W] embedding (post-ReLU trunk output) supplied by the caller
+  const float* rough_in;      // RSN_MODE_EMB: optional explicit roughness for the SH attenuation (get_mid's argument)
   rsn_field_saved saved;      // training: activations kept for the backward pass (all NULL in eval)
   long long act_stride;       // floats between consecutive layers in saved.act (= n_points_max * W)
 };
@@ -191,9 +193,18 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
 
-    // ---------------- encode -----------------
-    float mc[3], vc[3], vd[3];
+    float mc[3] = {0.0f, 0.0f, 0.0f}, vc[3] = {0.0f, 0.0f, 0.0f}, vd[3] = {0.0f, 0.0f, 0.0f};
     bool has_cov = true, has_dir = true;
+    if (a.mode == RSN_MODE_EMB) {
+      // granular Field API: heads / mid MLP on a caller-supplied embedding (field.py:139-186)
+      has_dir = a.view_dirs != nullptr;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vd[c] = has_dir ? a.view_dirs[pc * 3 + c] : 0.0f;
+#pragma unroll 4
+      for (int it = 0; it < NB * 4; ++it)
+        X[it * 64] = *reinterpret_cast<const float4*>(a.emb_in + pc * W + it * 8 + 4 * h);
+    } else {
+    // ---------------- encode -----------------
     if (a.mode == RSN_MODE_FRUSTUM) {
       const long long ray = pc / a.S;
       const int s = (int)(pc - ray * a.S);
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + l * a.act_stride + pc * W : nullptr, h);
       }
     }
+    }  // mode != RSN_MODE_EMB
     if (a.embedding && valid) {
 #pragma unroll 4
       for (int it = 0; it < NB * 4; ++it)
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       const float r4 = acc[NB][4], r5 = acc[NB][5], r6 = acc[NB][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
       const float rough_raw = __shfl(r4, m, 64);
-      rho = softplus_f(rough_raw);
+      rho = (a.mode == RSN_MODE_EMB && a.rough_in) ? a.rough_in[pc] : softplus_f(rough_raw);
       dcol[0] = sigmoid_f(r0); dcol[1] = sigmoid_f(r1); dcol[2] = sigmoid_f(r2);
       tcol[0] = sigmoid_f(r4); tcol[1] = sigmoid_f(r5); tcol[2] = sigmoid_f(r6);
       if (a.mode != RSN_MODE_INF && valid) {
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         const float m2 = sigmoid_f(accr[0][2]);
         if (TRAIN && a.saved.heads) *reinterpret_cast<float4*>(a.saved.heads + pc * 8 + 4) = make_float4(m0, m1, m2, 0.0f);
         if (a.out.color) {
-          if (a.mode == RSN_MODE_INF) {
+          if (a.mode == RSN_MODE_INF || (a.mode == RSN_MODE_EMB && !a.out.diff && !a.out.tint)) {
             a.out.color[pc * 3 + 0] = m0; a.out.color[pc * 3 + 1] = m1; a.out.color[pc * 3 + 2] = m2;
           } else {
             a.out.color[pc * 3 + 0] = dcol[0] + tcol[0] * m0;
@@ -586,6 +598,21 @@ extern "C" int rsn_field_forward_inf_train(const rsn_field_desc* desc, const flo
   a.out.color = out_rgb;
   a.saved = *saved;
   a.saved.normals = nullptr;
+  return launch_field(desc, a, stream);
+}
+
+extern "C" int rsn_field_forward_embedding(const rsn_field_desc* desc, const float* packed, int32_t n_points,
+                                           const float* embedding, const float* view_dirs, const float* roughness,
+                                           const rsn_field_outputs* out, void* stream) {
+  RSN_REQUIRE(desc && out, RSN_ERR_INVALID_ARGUMENT, "desc/out is NULL");
+  RSN_REQUIRE(n_points >= 0, RSN_ERR_INVALID_ARGUMENT, "n_points=%d", n_points);
+  RSN_REQUIRE(n_points == 0 || embedding, RSN_ERR_INVALID_ARGUMENT, "embedding is NULL");
+  FieldArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_EMB;
+  a.n_rays = n_points; a.n_dev = nullptr; a.S = 1;
+  a.emb_in = embedding; a.view_dirs = view_dirs; a.rough_in = roughness;
+  a.out = *out;
   return launch_field(desc, a, stream);
 }
 

@@ -9,6 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RSN_MODE_FRUSTUM 0
 #define RSN_MODE_INF 1
 #define RSN_MODE_GAUSS 2
+#define RSN_MODE_EMB 3
 
 // ------------------------------------------------------------------------------------------------
 // small math, written to follow the torch op order of the reference (contraction off: -ffp-contract=off)

@@ -670,3 +670,118 @@ extern "C" int rsn_reflect_default_backward(int32_t n_rays, const uint8_t* mask,
   RSN_HIP(hipGetLastError());
   return RSN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// granular geometry kernels (Field.get_blob / contract / get_reflection): one thread per sample
+// ---------------------------------------------------------------------------------------------------
+__global__ void rsn_gaussians_kernel(long long n, const float* o_, const float* d_, const float* pa_, const float* t0_,
+                                     const float* t1_, float* mean, float* cov) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float o[3], d[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { o[c] = o_[p * 3 + c]; d[c] = d_[p * 3 + c]; }
+  const float radius = sqrtf(pa_[p]) / 1.7724538509055159f;
+  const float mu = (t0_[p] + t1_[p]) / 2.0f, hw = (t1_[p] - t0_[p]) / 2.0f;
+  const float hw2 = hw * hw, mu2 = mu * mu, den = 3.0f * mu2 + hw2, hw4 = hw2 * hw2;
+  const float tmean = mu + (2.0f * mu * hw2) / den;
+  const float var_t = hw2 / 3.0f - 0.26666666666666666f * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+  const float var_r = (radius * radius) * (mu2 / 4.0f + 0.4166666666666667f * hw2 - (0.26666666666666666f * hw4) / den);
+  const float dmag = fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    mean[p * 3 + i] = o[i] + d[i] * tmean;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      cov[p * 9 + i * 3 + j] = var_t * (d[i] * d[j]) + var_r * ((i == j ? 1.0f : 0.0f) - d[i] * (d[j] / dmag));
+  }
+}
+
+__global__ void rsn_contract_kernel(long long n, const float* mean_, const float* cov_, float* mo, float* co) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float m[3], S[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    m[i] = mean_[p * 3 + i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S[i][j] = cov_[p * 9 + i * 3 + j];
+  }
+  const float n2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+  const float nn = sqrtf(n2);
+  const bool outside = nn > 1.0f;
+  float J[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float eye = (i == j) ? 1.0f : 0.0f;
+      J[i][j] = outside ? ((2.0f * nn - 2.0f) * (eye - m[i] * m[j] / n2) + eye) / n2 : eye;
+    }
+  const float sc = (2.0f * nn - 1.0f) / n2;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) mo[p * 3 + i] = outside ? sc * m[i] : m[i];
+  float JS[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) JS[i][b] = J[i][0] * S[0][b] + J[i][1] * S[1][b] + J[i][2] * S[2][b];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v = JS[i][0] * J[0][k] + JS[i][1] * J[1][k] + JS[i][2] * J[2][k];
+      if (i == k) v = fmaxf(v, 0.0f);
+      co[p * 9 + i * 3 + k] = v;
+    }
+}
+
+__global__ void rsn_reflection_kernel(long long n, const float* d_, const float* n_, float* refl, float* ndd) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float d0 = d_[p * 3], d1 = d_[p * 3 + 1], d2 = d_[p * 3 + 2];
+  const float n0 = n_[p * 3], n1 = n_[p * 3 + 1], n2 = n_[p * 3 + 2];
+  const float dot = d0 * n0 + d1 * n1 + d2 * n2;
+  if (ndd) ndd[p] = dot;
+  if (refl) {
+    const float r0 = d0 - 2.0f * dot * n0, r1 = d1 - 2.0f * dot * n1, r2 = d2 - 2.0f * dot * n2;
+    const float len = fmaxf(sqrtf(r0 * r0 + r1 * r1 + r2 * r2), 1e-12f);
+    refl[p * 3] = r0 / len; refl[p * 3 + 1] = r1 / len; refl[p * 3 + 2] = r2 / len;
+  }
+}
+
+#define RSN_ELEMENTWISE_LAUNCH(kernel, n, ...)                                                          \
+  do {                                                                                                  \
+    const int threads = 256;                                                                            \
+    const long long blocks = ((n) + threads - 1) / threads;                                             \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, (long long)(n), __VA_ARGS__); \
+    RSN_HIP(hipGetLastError());                                                                         \
+  } while (0)
+
+extern "C" int rsn_gaussians(int64_t n, const float* origins, const float* directions, const float* pixel_area,
+                             const float* starts, const float* ends, float* mean, float* cov, void* stream) {
+  RSN_REQUIRE(n >= 0, RSN_ERR_INVALID_ARGUMENT, "n=%lld", (long long)n);
+  if (n == 0) return RSN_OK;
+  RSN_REQUIRE(origins && directions && pixel_area && starts && ends && mean && cov, RSN_ERR_INVALID_ARGUMENT,
+              "a pointer is NULL");
+  RSN_ELEMENTWISE_LAUNCH(rsn_gaussians_kernel, n, origins, directions, pixel_area, starts, ends, mean, cov);
+  return RSN_OK;
+}
+
+extern "C" int rsn_contract(int64_t n, const float* mean, const float* cov, float* mean_out, float* cov_out,
+                            void* stream) {
+  RSN_REQUIRE(n >= 0, RSN_ERR_INVALID_ARGUMENT, "n=%lld", (long long)n);
+  if (n == 0) return RSN_OK;
+  RSN_REQUIRE(mean && cov && mean_out && cov_out, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  RSN_ELEMENTWISE_LAUNCH(rsn_contract_kernel, n, mean, cov, mean_out, cov_out);
+  return RSN_OK;
+}
+
+extern "C" int rsn_reflection(int64_t n, const float* directions, const float* normals, float* reflections,
+                              float* n_dot_d, void* stream) {
+  RSN_REQUIRE(n >= 0, RSN_ERR_INVALID_ARGUMENT, "n=%lld", (long long)n);
+  if (n == 0) return RSN_OK;
+  RSN_REQUIRE(directions && normals, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  RSN_ELEMENTWISE_LAUNCH(rsn_reflection_kernel, n, directions, normals, reflections, n_dot_d);
+  return RSN_OK;
+}

@@ -267,6 +267,103 @@ class ReflectSamplingNeRFNerfField(Field):
         self._last_level = {k: v.reshape(*shp, -1) for k, v in lv.items()}
         return self._last_level["sigma"], self._last_level["embedding"]
 
+    # -- geometry ------------------------------------------------------------------------------------------------
+    def get_blob(self, ray_samples):
+        """field.py:90-96: (mean [...,3], cov [...,3,3]) of the conical frustums of `ray_samples` (any object with a
+        `.frustums` carrying origins, directions, starts, ends, pixel_area; broadcastable)."""
+        lib = _abi.load_library()
+        fr = ray_samples.frustums
+        shp = torch.broadcast_shapes(fr.origins.shape[:-1], fr.directions.shape[:-1], fr.starts.shape[:-1],
+                                     fr.ends.shape[:-1], fr.pixel_area.shape[:-1])
+        ex = lambda t, c: ops._f32c(t.expand(*shp, c).reshape(-1, c))  # noqa: E731
+        o, d = ex(fr.origins, 3), ex(fr.directions, 3)
+        pa, t0, t1 = ex(fr.pixel_area, 1).reshape(-1), ex(fr.starts, 1).reshape(-1), ex(fr.ends, 1).reshape(-1)
+        n = o.shape[0]
+        mean = torch.empty(n, 3, device=o.device)
+        cov = torch.empty(n, 3, 3, device=o.device)
+        check(lib.rsn_gaussians(n, ptr(o), ptr(d), ptr(pa), ptr(t0), ptr(t1), ptr(mean), ptr(cov), ops._stream()))
+        return mean.reshape(*shp, 3), cov.reshape(*shp, 3, 3)
+
+    def contract(self, mean: Tensor, cov: Tensor, mask_return: bool = False):
+        """field.py:98-119: mip-NeRF-360 contraction of Gaussians (J cov J, diagonal clamped >= 0)."""
+        lib = _abi.load_library()
+        shp = mean.shape[:-1]
+        m = ops._f32c(mean.reshape(-1, 3))
+        c = ops._f32c(cov.reshape(-1, 9))
+        mo, co = torch.empty_like(m), torch.empty_like(c)
+        check(lib.rsn_contract(m.shape[0], ptr(m), ptr(c), ptr(mo), ptr(co), ops._stream()))
+        mo, co = mo.reshape(*shp, 3), co.reshape(*shp, 3, 3)
+        if mask_return:
+            return mo, co, torch.linalg.vector_norm(mean, dim=-1, keepdim=True) > 1
+        return mo, co
+
+    def get_reflection(self, directions: Tensor, normals: Tensor):
+        """field.py:203-207: (normalised mirror reflection [...,3], n_dot_d [...,1])."""
+        lib = _abi.load_library()
+        shp = torch.broadcast_shapes(directions.shape[:-1], normals.shape[:-1])
+        d = ops._f32c(directions.expand(*shp, 3).reshape(-1, 3))
+        nrm = ops._f32c(normals.expand(*shp, 3).reshape(-1, 3))
+        refl, ndd = torch.empty_like(d), torch.empty(d.shape[0], device=d.device)
+        check(lib.rsn_reflection(d.shape[0], ptr(d), ptr(nrm), ptr(refl), ptr(ndd), ops._stream()))
+        return refl.reshape(*shp, 3), ndd.reshape(*shp, 1)
+
+    # -- head getters on a caller-supplied embedding (eval-mode forward; training goes through the fused graph) --
+    def _heads(self, embedding: Tensor, view_dirs: Optional[Tensor] = None, roughness: Optional[Tensor] = None,
+               mid_only: bool = False) -> Dict[str, Tensor]:
+        lib = _abi.load_library()
+        shp = embedding.shape[:-1]
+        e = ops._f32c(embedding.reshape(-1, self.width))
+        N, dev = e.shape[0], e.device
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        lv = {"color": f(N, 3)}
+        if not mid_only:
+            lv.update({"pred_normals": f(N, 3), "diff": f(N, 3), "tint": f(N, 3), "roughness": f(N),
+                       "raw_density": f(N), "sigma": f(N)})
+        vd = None if view_dirs is None else ops._f32c(view_dirs.expand(*shp, 3).reshape(-1, 3))
+        rg = None if roughness is None else ops._f32c(roughness.expand(*shp, 1).reshape(-1))
+        fo = ops.field_outputs_struct(lv)
+        desc = self.field_desc()
+        check(lib.rsn_field_forward_embedding(C.byref(desc), ptr(self.packed_weights()), N, ptr(e), ptr(vd), ptr(rg),
+                                              C.byref(fo), ops._stream()))
+        return {k: v.reshape(*shp, -1) for k, v in lv.items()}
+
+    def get_pred_normals(self, embedding: Tensor) -> Tensor:
+        """field.py:139-144."""
+        return self._heads(embedding)["pred_normals"]
+
+    def get_normals(self) -> Tensor:
+        """field.py:146-147: analytic normals need the training graph; the fused training forward returns them as
+        outputs["normals_*"] (rsn_field_forward_frustum_train)."""
+        raise NotImplementedError("analytic normals are produced by the fused training forward (outputs['normals_*'])")
+
+    def get_roughness(self, embedding: Tensor, activation: Optional[nn.Module] = None) -> Tensor:
+        """field.py:150-155: activation(roughness head); default Sigmoid."""
+        sig = self._heads(embedding)["roughness"]
+        if activation is None or isinstance(activation, nn.Sigmoid):
+            return sig
+        raw = torch.logit(sig)  # the kernel returns sigmoid(raw); other activations are applied to raw
+        return activation(raw)
+
+    def get_diff(self, embedding: Tensor) -> Tensor:
+        """field.py:176-180."""
+        return self._heads(embedding)["diff"]
+
+    def get_tint(self, embedding: Tensor) -> Tensor:
+        """field.py:182-186."""
+        return self._heads(embedding)["tint"]
+
+    def get_mid(self, directions: Tensor, roughness: Tensor, embedding: Tensor, use_bottleneck: bool = True) -> Tensor:
+        """field.py:167-174: sigmoid RGB of mlp_mid(cat[SH34(directions, roughness), bottleneck(embedding)])."""
+        if not use_bottleneck:
+            raise NotImplementedError("use_bottleneck=False is not used by the reference model")
+        return self._heads(embedding, view_dirs=directions, roughness=roughness, mid_only=True)["color"]
+
+    def get_low(self, embedding: Tensor, use_bottleneck: bool = True) -> Tensor:
+        """field.py:158-164 (unused by the model): get_mid with the SH inputs zeroed."""
+        if not use_bottleneck:
+            raise NotImplementedError("use_bottleneck=False is not used by the reference model")
+        return self._heads(embedding, view_dirs=None, roughness=None, mid_only=True)["color"]
+
     def get_inf_color(self, directions: Tensor, sqradius: Tensor) -> Tensor:
         """field.py:190-201."""
         shp = directions.shape[:-1]

@@ -503,3 +503,75 @@ def test_get_outputs_bf16x6_meets_fp32_tolerance(dev):
               "accumulation_fine", "weights_fine", "diff", "tint", "roughness"):
         assert max_abs(out[k].cpu(), ref[k]) <= TOL, k
     assert torch.equal(out["mask"].cpu(), ref["mask"])
+
+
+# ---------------------------------------------------------------------------------------------- granular Field API
+def test_granular_field_api(dev):
+    """The Field methods the reference Model calls one by one: get_blob, contract, get_density,
+    get_pred_normals, get_diff, get_tint, get_roughness, get_mid, get_low, get_reflection -- against the oracle, and
+    contract against the golden vectors captured from the reference's own Field.contract."""
+    from types import SimpleNamespace
+
+    fld, P, fs = make_field(8, 128, dev, seed=21)
+    R, S = 7, 9
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=5)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    _, eb = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S, None)
+    t0, t1 = eb[:, :-1], eb[:, 1:]
+    fr = SimpleNamespace(origins=o[:, None, :].to(dev), directions=d[:, None, :].to(dev), starts=t0[..., None].to(dev),
+                         ends=t1[..., None].to(dev), pixel_area=pa[:, None, :].to(dev))
+    mean, cov = fld.get_blob(SimpleNamespace(frustums=fr))
+    mean_ref, cov_ref = cpu_ref.gaussian_blob(o, d, pa, t0, t1)
+    assert mean.shape == (R, S, 3) and cov.shape == (R, S, 3, 3)
+    assert max_abs(mean.cpu(), mean_ref) <= 1e-6 and max_abs(cov.cpu(), cov_ref) <= 1e-8
+    # contract: golden from the reference's own method (points inside and far outside the unit ball)
+    _, g = load_golden("units")
+    c = g["contract"]
+    mc, cc = fld.contract(c["mean"].to(dev), c["cov"].to(dev))
+    assert max_abs(mc.cpu(), c["out_mean"]) <= 2e-6 and max_abs(cc.cpu(), c["out_cov"]) <= 2e-6
+    # density + head getters
+    mean_c, cov_c = cpu_ref.contract(mean_ref, cov_ref)
+    with torch.no_grad():
+        enc = cpu_ref.ipe(fs, mean_c, torch.diagonal(cov_c, dim1=-2, dim2=-1))
+        sig_ref, emb_ref, _ = cpu_ref.density_from_encoding(P, fs, enc)
+    sig, emb = fld.get_density(mean_c.to(dev), cov_c.to(dev))
+    assert max_abs(sig.cpu(), sig_ref) <= TOL and max_abs(emb.cpu(), emb_ref) <= TOL
+    with torch.no_grad():
+        pn_ref = cpu_ref.pred_normals(P, emb_ref)
+        diff_ref = torch.sigmoid(cpu_ref.head(P, "field_output_diff", emb_ref))
+        tint_ref = torch.sigmoid(cpu_ref.head(P, "field_output_tint", emb_ref))
+        rr = cpu_ref.head(P, "field_output_roughness", emb_ref)
+        dirs = d[:, None, :].expand(R, S, 3)
+        rough = torch.rand(R, S, 1) * 1.5
+        mid_ref = cpu_ref.mid_color(P, fs, cpu_ref.integrated_sh(dirs, rough), emb_ref)
+        low_ref = cpu_ref.mid_color(P, fs, torch.zeros(R, S, 34), emb_ref)
+    emb_dev = emb_ref.to(dev)
+    assert max_abs(fld.get_pred_normals(emb_dev).cpu(), pn_ref) <= TOL_UNIT
+    assert max_abs(fld.get_diff(emb_dev).cpu(), diff_ref) <= TOL
+    assert max_abs(fld.get_tint(emb_dev).cpu(), tint_ref) <= TOL
+    assert max_abs(fld.get_roughness(emb_dev).cpu(), torch.sigmoid(rr)) <= TOL
+    assert max_abs(fld.get_roughness(emb_dev, torch.nn.Softplus()).cpu(), torch.nn.functional.softplus(rr)) <= TOL
+    assert max_abs(fld.get_mid(dirs.to(dev), rough.to(dev), emb_dev).cpu(), mid_ref) <= TOL
+    assert max_abs(fld.get_low(emb_dev).cpu(), low_ref) <= TOL
+    refl, ndd = fld.get_reflection(dirs.to(dev), pn_ref.to(dev))
+    ndd_ref = torch.sum(dirs * pn_ref, dim=-1, keepdim=True)
+    refl_ref = torch.nn.functional.normalize(dirs - 2 * ndd_ref * pn_ref, dim=-1)
+    assert max_abs(ndd.cpu(), ndd_ref) <= 1e-6 and max_abs(refl.cpu(), refl_ref) <= 1e-6
+
+
+def test_camera_ray_bundle_chunked_eval(dev):
+    """Model.get_outputs_for_camera_ray_bundle: chunks of eval_num_rays_per_chunk rays, reshaped to the image."""
+    torch.manual_seed(3)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=16, num_importance_samples=16,
+                                            num_reflect_coarse_samples=8, num_reflect_importance_samples=8,
+                                            base_mlp_num_layers=4, base_mlp_layer_width=64, eval_num_rays_per_chunk=100)
+    model = cfg.setup(scene_box=None, num_train_data=1).to(dev).eval()
+    H, Wd = 12, 21
+    o, d, pa = cpu_ref.synthetic_rays(H * Wd, seed=9)
+    rb = pkg.RayBundle(origins=o.reshape(H, Wd, 3).to(dev), directions=d.reshape(H, Wd, 3).to(dev),
+                       pixel_area=pa.reshape(H, Wd, 1).to(dev))
+    img = model.get_outputs_for_camera_ray_bundle(rb)
+    assert img["mid_rgb_fine"].shape == (H, Wd, 3) and img["accumulation_fine"].shape == (H, Wd, 1)
+    flat = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev))
+    whole = model(flat)
+    assert max_abs(img["mid_rgb_fine"].reshape(-1, 3), whole["mid_rgb_fine"]) <= 1e-6
