@@ -58,9 +58,10 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict
     __builtin_amdgcn_sched_barrier(0);
     mma4<NBO>(acc, wa, ba);
     __builtin_amdgcn_sched_barrier(0);
-    if (it + 2 < n_it) {
-      load_w<NBO>(wa, wp, it + 2);
-      ba = xl[(it + 2) * 64];
+    {  // unconditional prefetch with a clamped index: one control path => exact vmcnt counts
+      const int in = (it + 2 < n_it) ? it + 2 : n_it - 1;
+      load_w<NBO>(wa, wp, in);
+      ba = xl[in * 64];
     }
     __builtin_amdgcn_sched_barrier(0);
     mma4<NBO>(acc, wb, bb);
@@ -149,21 +150,34 @@ template <int NBO, int NSPLIT>
 __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl,
                                           int n_k16, int lane) {
   constexpr int H0 = (NBO + 1) / 2, H1 = NBO - H0;
+  constexpr int PER = (NSPLIT == 3 ? 6 : 3);  // MFMAs per output block and K step
   const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(wseg) + lane;
   bf16x8 wa[H0][3], wb[H1 > 0 ? H1 : 1][3];
   load_w16<H0, NSPLIT>(wa, wp, 0, NBO, 0);
   BSplit bc = split8<NSPLIT>(xl[0], xl[64]);
+  const int k1 = n_k16 > 1 ? 1 : 0;
+  float4 xlo = xl[(2 * k1) * 64], xhi = xl[(2 * k1 + 1) * 64];  // fp32 activations of the NEXT K step
 #pragma unroll 1
   for (int kk = 0; kk < n_k16; ++kk) {
+    // ---- phase A: first-half MFMAs; the 3-way split of the next step's activations rides in their issue gaps
+    //      (matrix and vector pipes are separate; one 32-cycle MFMA leaves room for a few single-issue VALU ops)
     if (H1 > 0) load_w16<(H1 > 0 ? H1 : 1), NSPLIT>(wb, wp, kk, NBO, H0);
     __builtin_amdgcn_sched_barrier(0);
+    const BSplit bn = split8<NSPLIT>(xlo, xhi);
     mma16<NBO, H0, 0, NSPLIT>(acc, wa, bc);
-    __builtin_amdgcn_sched_barrier(0);
-    BSplit bn = bc;
-    if (kk + 1 < n_k16) {
-      load_w16<H0, NSPLIT>(wa, wp, kk + 1, NBO, 0);
-      bn = split8<NSPLIT>(xl[(2 * kk + 2) * 64], xl[(2 * kk + 3) * 64]);
+#pragma unroll
+    for (int g = 0; g < H0 * PER; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B: prefetch (unconditional, clamped: one control path keeps the s_waitcnt counts exact), then the
+    //      second-half MFMAs
+    const int kn = (kk + 1 < n_k16) ? kk + 1 : kk;
+    const int k2 = (kk + 2 < n_k16) ? kk + 2 : kn;
+    load_w16<H0, NSPLIT>(wa, wp, kn, NBO, 0);
+    xlo = xl[(2 * k2) * 64];
+    xhi = xl[(2 * k2 + 1) * 64];
     __builtin_amdgcn_sched_barrier(0);
     if (H1 > 0) mma16<NBO, (H1 > 0 ? H1 : 1), (H1 > 0 ? H0 : 0), NSPLIT>(acc, wb, bc);
     __builtin_amdgcn_sched_barrier(0);
