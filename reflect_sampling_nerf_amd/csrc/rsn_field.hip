@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
         const float ang = sx * f;
         const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
-        const float fs = e * sinf(ang);
-        const float fc = e * sinf(ang + 1.5707963267948966f);
+        const float fs = e * sin_big(ang);
+        const float fc = e * sin_big(ang + 1.5707963267948966f);
         const int u = c * 8 + jj;
         Xf[(u >> 2) * 256 + (u & 3)] = fs;
         Xf[((u + 24) >> 2) * 256 + ((u + 24) & 3)] = fc;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           const int u = c * 8 + jj;
           const float gs = Xf[(u >> 2) * 256 + (u & 3)];
           const float gc = Xf[((u + 24) >> 2) * 256 + ((u + 24) & 3)];
-          part += (gs * (e * cosf(ang)) + gc * (e * cosf(ang + 1.5707963267948966f))) * f;
+          part += (gs * (e * cos_big(ang)) + gc * (e * cos_big(ang + 1.5707963267948966f))) * f;
         }
         part *= 6.283185307179586f;
         if (h == 0) part += Xf[12 * 256 + c];  // the raw-coordinate input column

@@ -3,15 +3,16 @@
 import collections, csv, glob, json, os, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "rsn_field_kernel<8, false, 0>"  # exact-fp32 eval instantiation
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-out = {"tag": tag}
+out = {"tag": tag, "kernel": KERNEL}
 # 1. kernel stats
 f = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
 stats = list(csv.DictReader(open(f)))
 out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                         "pct": float(r["Percentage"])} for r in stats]
-fk = next(r for r in stats if "rsn_field_kernel" in r["Name"])
+fk = next(r for r in stats if KERNEL in r["Name"])
 out["field_kernel_avg_ms"] = float(fk["AverageNs"]) / 1e6
 # 2. PMC
 pmc = {}
@@ -21,7 +22,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         continue
     agg, dur = collections.defaultdict(list), []
     for r in csv.DictReader(open(fs[0])):
-        if "rsn_field_kernel" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in agg.items():
@@ -49,7 +50,7 @@ with open(f"profiles/{tag}_summary.md", "w") as w:
     w.write("## --kernel-trace --stats\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
     for k in out["kernel_stats"]:
         w.write(f"| `{k['name']}` | {k['calls']} | {k['avg_us']:.1f} | {k['pct']:.3f} |\n")
-    w.write("\n## PMC, rsn_field_kernel<8> (per launch, mean)\n\n| counter | value |\n|---|---|\n")
+    w.write(f"\n## PMC, {KERNEL} (per launch, mean)\n\n| counter | value |\n|---|---|\n")
     for k, v in sorted(pmc.items()):
         w.write(f"| {k} | {v:.5g} |\n")
     w.write("\n## derived\n\n")
