@@ -45,7 +45,7 @@ def parse():
                     help="level = BASELINE configs[1] (default); get_outputs = full eval get_outputs "
                          "(coarse+fine+reflect); train = BASELINE configs[2]: full training step (forward, loss, "
                          "backward, gradient all-reduce, RAdam) with 64 coarse + 128 fine + reflect 64+64 samples")
-    ap.add_argument("--mma", default="f32", choices=["f32", "bf16x6", "bf16x3"],
+    ap.add_argument("--mma", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="matrix-core arithmetic of the eval field kernel: f32 = exact fp32 MFMA (default); bf16x6 = "
                          "fp32 emulation by 3-way bf16 splits (fp32-equivalent results); bf16x3 = reduced precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -230,7 +230,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "f32 (emulated: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate)",
-                      "bf16x3": "bf16x3 (2-way bf16 split, f32 accumulate; reduced precision)"}[args.mma],
+                      "bf16x3": "bf16x3 (2-way bf16 split, f32 accumulate; reduced precision)",
+                      "bf16": "bf16 (bf16 MFMA operands, f32 accumulate; BASELINE configs[3])"}[args.mma],
             "data": "synthetic",
             "config": {
                 "workload": ("BASELINE configs[1]: %d rays x %d samples, %d-layer %d-wide MLP, fp32, fused forward + "
@@ -263,10 +264,10 @@ def main():
                     pass
                 # f32: algorithmic FLOP against the fp32-MFMA peak.  Split modes issue 6 (3) bf16 MFMA FLOP per
                 # algorithmic FLOP: priced as issued bf16 FLOP against the bf16 dense peak.
-                mult = {"f32": 1, "bf16x6": 6, "bf16x3": 3}[args.mma]
+                mult = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}[args.mma]
                 peak = FP32_MFMA_PEAK_TFLOPS if args.mma == "f32" else BF16_MFMA_PEAK_TFLOPS
                 line["roofline"] = {
-                    "kernel": "rsn_field_kernel<8,false,%d>" % {"f32": 0, "bf16x6": 1, "bf16x3": 2}[args.mma],
+                    "kernel": "rsn_field_kernel<8,false,%d>" % {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}[args.mma],
                     "bound": "mfma",
                     "achieved": achieved * mult,
                     "algorithmic_tflops": achieved,

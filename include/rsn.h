@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 5
+#define RSN_ABI_VERSION 6
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -65,8 +65,10 @@ typedef struct rsn_field_desc {
  *   RSN_MMA_BF16X6  fp32 emulation: both operands split exactly into 3 bf16 (8+8+8 mantissa bits), the 6 leading
  *                   cross products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-24
  *                   relative): fp32-equivalent results at 6/16 of the fp32-MFMA cost;
- *   RSN_MMA_BF16X3  2-way split, 3 products (~2^-16 relative): reduced precision, opt-in only. */
-typedef enum rsn_mma_mode { RSN_MMA_F32 = 0, RSN_MMA_BF16X6 = 1, RSN_MMA_BF16X3 = 2 } rsn_mma_mode;
+ *   RSN_MMA_BF16X3  2-way split, 3 products (~2^-16 relative): reduced precision, opt-in only;
+ *   RSN_MMA_BF16    plain bf16 operands (1 product, 8 mantissa bits), fp32 accumulate: BASELINE configs[3]
+ *                   ("bf16 MFMA hidden GEMMs"); encode, heads' activations and compositing stay fp32. */
+typedef enum rsn_mma_mode { RSN_MMA_F32 = 0, RSN_MMA_BF16X6 = 1, RSN_MMA_BF16X3 = 2, RSN_MMA_BF16 = 3 } rsn_mma_mode;
 
 /* Parameters in torch.nn.Linear layout: weight [out,in] row-major, bias [out]; names follow the
  * reference Field's state_dict (reflect_sampling_nerf_field.py:54-86).  field_output_low (:67) is

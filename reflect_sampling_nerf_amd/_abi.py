@@ -9,12 +9,12 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 5
+RSN_ABI_VERSION = 6
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
 RSN_SPACING_RECIPROCAL = 1
-RSN_MMA_F32, RSN_MMA_BF16X6, RSN_MMA_BF16X3 = 0, 1, 2
+RSN_MMA_F32, RSN_MMA_BF16X6, RSN_MMA_BF16X3, RSN_MMA_BF16 = 0, 1, 2, 3
 
 _fp = C.c_void_p  # device float*
 

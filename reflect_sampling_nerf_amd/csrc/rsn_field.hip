@@ -515,6 +515,8 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
       hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
     else if (mode == RSN_MMA_BF16X3)                                                                            \
       hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
+    else if (mode == RSN_MMA_BF16)                                                                              \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
     else                                                                                                         \
       hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
   } while (0)

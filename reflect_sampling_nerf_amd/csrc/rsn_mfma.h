@@ -131,7 +131,7 @@ __device__ __forceinline__ BSplit split8(const float4 lo, const float4 hi) {
   for (int e = 0; e < 8; ++e) {
     const __bf16 b1 = (__bf16)x[e];
     const float r1 = x[e] - (float)b1;
-    const __bf16 b2 = (__bf16)r1;
+    const __bf16 b2 = (NSPLIT >= 2) ? (__bf16)r1 : (__bf16)0.0f;
     o.s1[e] = b1;
     o.s2[e] = b2;
     if (NSPLIT == 3) {
@@ -162,8 +162,10 @@ __device__ __forceinline__ void mma16(f32x16 (&acc)[NBO], const bf16x8 (&w)[NH][
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][1], b.s2, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][0], b.s3, c, 0, 0, 0);
     }
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][1], b.s1, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][0], b.s2, c, 0, 0, 0);
+    if (NSPLIT >= 2) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][1], b.s1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][0], b.s2, c, 0, 0, 0);
+    }
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][0], b.s1, c, 0, 0, 0);
     acc[NB0 + t] = c;
   }
@@ -173,7 +175,7 @@ template <int NBO, int NSPLIT>
 __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl,
                                           int n_k16, int lane) {
   constexpr int H0 = (NBO + 1) / 2, H1 = NBO - H0;
-  constexpr int PER = (NSPLIT == 3 ? 6 : 3);  // MFMAs per output block and K step
+  constexpr int PER = (NSPLIT == 3 ? 6 : (NSPLIT == 2 ? 3 : 1));  // MFMAs per output block and K step
   const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(wseg) + lane;
   bf16x8 wa[H0][3], wb[H1 > 0 ? H1 : 1][3];
   load_w16<H0, NSPLIT>(wa, wp, 0, NBO, 0);
@@ -215,7 +217,7 @@ __device__ __forceinline__ void gemm_mode(f32x16 (&acc)[NBO], const float* __res
   if (MODE == 0) {
     gemm<NBO>(acc, w32, xl, n_it, lane);
   } else {
-    gemm_bf16<NBO, (MODE == 1 ? 3 : 2)>(acc, w16, xl, (n_it + 1) / 2, lane);
+    gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
   }
 }
 

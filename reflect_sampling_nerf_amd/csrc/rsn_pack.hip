@@ -33,7 +33,7 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   RSN_REQUIRE(d->width == 64 || d->width == 128 || d->width == 256, RSN_ERR_UNSUPPORTED,
               "width=%d unsupported (64, 128 or 256)", d->width);
   RSN_REQUIRE(d->mid_width == 128, RSN_ERR_UNSUPPORTED, "mid_width=%d unsupported (128)", d->mid_width);
-  RSN_REQUIRE(d->mma_mode >= RSN_MMA_F32 && d->mma_mode <= RSN_MMA_BF16X3, RSN_ERR_INVALID_ARGUMENT, "mma_mode=%d",
+  RSN_REQUIRE(d->mma_mode >= RSN_MMA_F32 && d->mma_mode <= RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "mma_mode=%d",
               d->mma_mode);
   RSN_REQUIRE(d->skip_layer == -1 || (d->skip_layer >= 1 && d->skip_layer <= d->num_layers - 2),
               RSN_ERR_INVALID_ARGUMENT,

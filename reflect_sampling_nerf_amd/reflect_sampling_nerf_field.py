@@ -109,11 +109,13 @@ class ReflectSamplingNeRFNerfField(Field):
         self._desc: Optional[FieldDesc] = None
         self.mma_mode = _abi.RSN_MMA_F32
 
-    MMA_MODES = {"f32": _abi.RSN_MMA_F32, "bf16x6": _abi.RSN_MMA_BF16X6, "bf16x3": _abi.RSN_MMA_BF16X3}
+    MMA_MODES = {"f32": _abi.RSN_MMA_F32, "bf16x6": _abi.RSN_MMA_BF16X6, "bf16x3": _abi.RSN_MMA_BF16X3,
+                 "bf16": _abi.RSN_MMA_BF16}
 
     def set_mma_mode(self, mode: str) -> None:
         """Arithmetic of the dense GEMMs in the eval field kernel: "f32" (exact fp32 MFMA), "bf16x6" (fp32
-        emulation by 3-way bf16 splits, fp32-equivalent) or "bf16x3" (2-way split, reduced precision, opt-in)."""
+        emulation by 3-way bf16 splits, fp32-equivalent), "bf16x3" (2-way split, reduced precision, opt-in) or "bf16"
+        (plain bf16 operands, fp32 accumulate: BASELINE configs[3])."""
         self.mma_mode = self.MMA_MODES[mode]
         self._desc = None
 

@@ -460,7 +460,7 @@ def test_training_trajectory_and_psnr_match_oracle(dev):
 
 
 # ---------------------------------------------------------------------------------------------- split-bf16 MMA modes
-@pytest.mark.parametrize("mode,tol", [("bf16x6", 1e-4), ("bf16x3", 2e-3)])
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 1e-4), ("bf16x3", 2e-3), ("bf16", 3e-2)])
 @pytest.mark.parametrize("layers,width", [(8, 256), (4, 128), (8, 64)])
 def test_field_level_split_bf16_modes(dev, mode, tol, layers, width):
     """RSN_MMA_BF16X6 (fp32 emulation, must meet the fp32 tolerance) and RSN_MMA_BF16X3 (opt-in reduced precision)."""
@@ -477,7 +477,8 @@ def test_field_level_split_bf16_modes(dev, mode, tol, layers, width):
     assert max_abs(lv["sigma"].cpu(), ref["sigma"][..., 0]) <= tol
     assert max_abs(lv["color"].cpu(), ref["color"]) <= tol
     assert max_abs(lv["diff"].cpu(), ref["diff"]) <= tol
-    assert max_abs(lv["pred_normals"].cpu(), ref["pred_normals"]) <= max(tol, TOL_UNIT) * (10 if mode == "bf16x3" else 1)
+    if mode != "bf16":  # unit normals of a small raw vector amplify the 8-bit operand rounding: not bounded for bf16
+        assert max_abs(lv["pred_normals"].cpu(), ref["pred_normals"]) <= max(tol, TOL_UNIT) * (10 if mode == "bf16x3" else 1)
 
 
 def test_get_outputs_bf16x6_meets_fp32_tolerance(dev):
