@@ -437,10 +437,13 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
 #pragma unroll 1
       for (int l = a.num_layers - 1; l >= 1; --l) {
         if (l == a.skip_layer) gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, lane);
+        float4 mk[NB * 4];
+        load_mask<NB>(mk, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[NB];
         zero_acc<NB>(acc);
         gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, lane);
-        store_masked<NB>(acc, X, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
+        store_masked_pre<NB>(acc, X, mk, h);
       }
       gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, lane);
       store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)

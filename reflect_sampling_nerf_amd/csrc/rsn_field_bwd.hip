@@ -161,10 +161,13 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     X[0] = (h == 1) ? make_float4(dz_rgb[0], dz_rgb[1], dz_rgb[2], 0.0f) : zero4;
     X[64] = zero4; X[128] = zero4; X[192] = zero4;
     {
+      float4 mk[16];
+      load_mask<4>(mk, a.saved.hid + pc * 128, h);
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[4];
       zero_acc<4>(acc);
       gemm_mode<MODE, 4>(acc, pk + a.L.wT_rgb, pk + a.L.hT_rgb, X, 4, lane);
-      store_masked<4>(acc, X, a.saved.hid + pc * 128, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
+      store_masked_pre<4>(acc, X, mk, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
@@ -223,12 +226,14 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
         *reinterpret_cast<float4*>(a.gout.dz_heads + pc * 16 + 4 * h) = q0;
         *reinterpret_cast<float4*>(a.gout.dz_heads + pc * 16 + 8 + 4 * h) = q1;
       }
+      const int l = a.num_layers - 1;
+      float4 mk[NB * 4];
+      load_mask<NB>(mk, a.saved.act + (long long)l * a.act_stride + pc * W, h);
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_bh, pk + a.L.hT_bh, X, NB * 4 + 4, lane);
-      const int l = a.num_layers - 1;
-      store_masked<NB>(acc, X, a.saved.act + (long long)l * a.act_stride + pc * W, h,
-                       valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
+      store_masked_pre<NB>(acc, X, mk, h, valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
     f32x16 eacc[4];
@@ -237,11 +242,13 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     for (int l = a.num_layers - 1; l >= 1; --l) {
       if (a.need_input_grad && l == a.skip_layer)
         gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, lane);
+      float4 mk[NB * 4];
+      load_mask<NB>(mk, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, lane);
-      store_masked<NB>(acc, X, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h,
-                       valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
+      store_masked_pre<NB>(acc, X, mk, h, valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
     if (a.need_input_grad) {

@@ -250,6 +250,35 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
     }
 }
 
+// Prefetch of the ReLU-mask rows (saved post-ReLU activations) of a dX-sweep layer: issued BEFORE the layer's GEMM so
+// that the HBM round trip hides under its MFMAs (consuming them right after the load parked 30 % of the backward
+// kernel's wave cycles in s_waitcnt).
+template <int NBO>
+__device__ __forceinline__ void load_mask(float4 (&mk)[NBO * 4], const float* __restrict__ xin, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mk[nb * 4 + q] = *reinterpret_cast<const float4*>(xin + (nb * 4 + q) * 8 + 4 * h);
+}
+
+template <int NBO>
+__device__ __forceinline__ void store_masked_pre(const f32x16 (&acc)[NBO], float4* xl, const float4 (&mk)[NBO * 4], int h,
+                                                 float* save = nullptr) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 x = mk[nb * 4 + q];
+      float4 v;
+      v.x = x.x > 0.0f ? acc[nb][4 * q + 0] : 0.0f;
+      v.y = x.y > 0.0f ? acc[nb][4 * q + 1] : 0.0f;
+      v.z = x.z > 0.0f ? acc[nb][4 * q + 2] : 0.0f;
+      v.w = x.w > 0.0f ? acc[nb][4 * q + 3] : 0.0f;
+      xl[(nb * 4 + q) * 64] = v;
+      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+    }
+}
+
 // dX-sweep epilogue: X[it][lane] = (x_in > 0) ? acc : 0 with x_in = the saved post-ReLU input of the layer
 // (row `xin` of a row-major activation buffer); optionally also stored to row `save` (backward pass).
 template <int NBO>
