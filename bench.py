@@ -152,7 +152,7 @@ def main():
         from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, train_step
 
         params = model.get_param_groups()["fields"]
-        optimizer = torch.optim.RAdam(params, lr=1e-3, eps=1e-15)  # reference config.py:50-53
+        optimizer = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15, lr_final=1e-4, max_steps=50000)  # config.py:50-53
         reducer = FlatGradAllReduce(params) if world > 1 else None
         g = torch.Generator().manual_seed(1234 + rank)
         batch = {"image": torch.rand(R, 3, generator=g).to(dev)}

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 6
+#define RSN_ABI_VERSION 7
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -361,6 +361,27 @@ int rsn_reflect_combine(int32_t n_rays_max, const int32_t* n_masked, const int32
 int rsn_reflect_combine_backward(int32_t n_rays_max, const int32_t* n_masked, const int32_t* ray_index,
                                  const float* diff, const float* tint, const float* comp, const float* g_out,
                                  float* g_comp, void* stream);
+
+/* ---- the two steps after the hot path in a training iteration ------------------------
+ * rsn_loss_forward_backward: get_loss_dict (reflect_sampling_nerf_model.py:346-430).  Term order of losses8 /
+ * coef8: loss_mid_coarse, loss_mid_fine, loss_reflect_mid_coarse, loss_reflect_mid_fine (MSE means against `image`
+ * [R,3]), predicted_normal_loss_{coarse,fine} = sum w |normals - pred_normals|^2, orientation_loss_{coarse,fine} =
+ * sum w max(0, n_dot_d)^2.  losses8 (device, overwritten) receives the UNSCALED terms; the gradient outputs
+ * (w.r.t. rgb4, pred_normals2, n_dot_d2; all other inputs are constants of the loss) are scaled by coef8
+ * (host array, the model's loss_coefficients incl. the 50-step warm-up of reflect_sampling_nerf_pipeline.py:79-91).
+ * The *4 / *2 arguments are HOST arrays of device pointers (coarse, fine order). */
+int rsn_loss_forward_backward(int32_t n_rays, int32_t s_coarse, int32_t s_fine, const float* image,
+                              const float* const* rgb4, const float* const* weights2, const float* const* normals2,
+                              const float* const* pred_normals2, const float* const* n_dot_d2, const float* coef8,
+                              float* losses8, float* const* g_rgb4, float* const* g_pred_normals2,
+                              float* const* g_n_dot_d2, void* stream);
+
+/* rsn_radam_step: one RAdam update (torch.optim.RAdam semantics; the reference's optimiser for the "fields" group,
+ * reflect_sampling_nerf_config.py:50-53: lr 1e-3, eps 1e-15, betas 0.9/0.999) over all parameter tensors in one
+ * launch.  HOST arrays of device pointers; grads[t] == NULL skips tensor t (unused parameter); step counts from 1. */
+int rsn_radam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int32_t* sizes, int32_t step, float lr, float beta1, float beta2,
+                   float eps, void* stream);
 
 #ifdef __cplusplus
 }

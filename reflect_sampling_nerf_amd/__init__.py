@@ -15,6 +15,8 @@ from .reflect_sampling_nerf_components import (  # noqa: F401
 from .reflect_sampling_nerf_field import ReflectSamplingNeRFNerfField  # noqa: F401
 from .reflect_sampling_nerf_model import ReflectSamplingNeRFModel, ReflectSamplingNeRFModelConfig  # noqa: F401
 
+from .train_ops import FusedRAdam, exponential_decay_lr  # noqa: F401,E402
+
 __all__ = [
     "ReflectSamplingNeRFModel", "ReflectSamplingNeRFModelConfig", "ReflectSamplingNeRFNerfField", "RayBundle",
     "ReciprocalSampler", "IntegratedSHEncoding", "NeRFEncoding", "UniformSampler", "PDFSampler", "load_library",

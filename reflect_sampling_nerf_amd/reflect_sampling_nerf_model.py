@@ -195,24 +195,43 @@ class ReflectSamplingNeRFModel(Model):
 
     # ------------------------------------------------------------------ loss (model.py:346-430; "next" row §8(f).1)
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        """model.py:346-430: four MSE terms against the (white-blended) image, two predicted-normal and two
+        orientation terms, scaled by config.loss_coefficients.  One fused HIP pass (train_ops.FusedLoss)."""
+        from .train_ops import fused_loss_dict
+
         image = batch["image"].to(self.device)
         if image.shape[-1] == 4:  # RGBRenderer.blend_background with the white background colour
             image = image[..., :3] * image[..., 3:] + (1.0 - image[..., 3:])
-        loss_dict = {
-            "loss_mid_coarse": self.rgb_loss(image, outputs["mid_rgb_coarse"]),
-            "loss_mid_fine": self.rgb_loss(image, outputs["mid_rgb_fine"]),
-            "loss_reflect_mid_coarse": self.rgb_loss(image, outputs["mid_reflect_coarse"]),
-            "loss_reflect_mid_fine": self.rgb_loss(image, outputs["mid_reflect_fine"]),
-            "predicted_normal_loss_coarse": torch.sum(outputs["weights_coarse"] * torch.sum(
-                (outputs["normals_coarse"] - outputs["pred_normals_coarse"]) ** 2, dim=-1, keepdim=True)),
-            "predicted_normal_loss_fine": torch.sum(outputs["weights_fine"] * torch.sum(
-                (outputs["normals_fine"] - outputs["pred_normals_fine"]) ** 2, dim=-1, keepdim=True)),
-            "orientation_loss_coarse": torch.sum(
-                outputs["weights_coarse"] * torch.clamp(outputs["n_dot_d_coarse"], min=0.0) ** 2),
-            "orientation_loss_fine": torch.sum(
-                outputs["weights_fine"] * torch.clamp(outputs["n_dot_d_fine"], min=0.0) ** 2),
+        return fused_loss_dict(outputs, image, self.config.loss_coefficients)
+
+    # ------------------------------------------------------------------ eval image (model.py:432-482; "next" row §8(f).4)
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
+        """Working equivalent of the reference hook (which raises KeyError: 'low_coarse' at model.py:438): PSNR of the
+        coarse render and of the reflect-fine render against the white-blended ground truth, and the three panels the
+        reference assembles (rgb | accumulation | depth, coarse and fine side by side).  SSIM / LPIPS need the
+        torchmetrics networks and are out of scope."""
+        assert self.config.collider_params is not None, "mip-NeRF requires collider parameters to be set."
+        image = batch["image"].to(outputs["mid_rgb_coarse"].device)
+        if image.shape[-1] == 4:
+            image = image[..., :3] * image[..., 3:] + (1.0 - image[..., 3:])
+        rgb_coarse = torch.clip(outputs["mid_rgb_coarse"], 0.0, 1.0)
+        rgb_fine = torch.clip(outputs["mid_reflect_fine"], 0.0, 1.0)
+
+        def psnr(a, b):
+            return float(10.0 * torch.log10(1.0 / torch.mean((a - b) ** 2).clamp(min=1e-12)))
+
+        near, far = self.config.collider_params["near_plane"], self.config.collider_params["far_plane"]
+
+        def depth_panel(d, acc):
+            return (((d - near) / (far - near)).clamp(0.0, 1.0) * acc + (1.0 - acc)).expand(*d.shape[:-1], 3)
+
+        gray = lambda a: a.expand(*a.shape[:-1], 3)  # noqa: E731
+        images = {
+            "img": torch.cat([image, rgb_coarse, rgb_fine], dim=1),
+            "accumulation": torch.cat([gray(outputs["accumulation_coarse"]), gray(outputs["accumulation_fine"])], dim=1),
+            "depth": torch.cat([depth_panel(outputs["depth_coarse"], outputs["accumulation_coarse"]),
+                                depth_panel(outputs["depth_fine"], outputs["accumulation_fine"])], dim=1),
         }
-        for k in loss_dict:
-            if k in self.config.loss_coefficients:
-                loss_dict[k] = loss_dict[k] * self.config.loss_coefficients[k]
-        return loss_dict
+        fine_psnr = psnr(image, rgb_fine)
+        metrics = {"psnr": fine_psnr, "coarse_psnr": psnr(image, rgb_coarse), "fine_psnr": fine_psnr}
+        return metrics, images

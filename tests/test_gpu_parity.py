@@ -576,6 +576,11 @@ def test_camera_ray_bundle_chunked_eval(dev):
     flat = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev))
     whole = model(flat)
     assert max_abs(img["mid_rgb_fine"].reshape(-1, 3), whole["mid_rgb_fine"]) <= 1e-6
+    # the eval-image hook (the reference's own raises KeyError at model.py:438)
+    metrics, images = model.get_image_metrics_and_images(img, {"image": torch.rand(H, Wd, 3)})
+    assert set(metrics) == {"psnr", "coarse_psnr", "fine_psnr"} and metrics["psnr"] > 0
+    assert images["img"].shape == (H, 3 * Wd, 3) and images["accumulation"].shape == (H, 2 * Wd, 3)
+    assert images["depth"].shape == (H, 2 * Wd, 3)
 
 
 # ---------------------------------------------------------------------------------------------- edge shapes
@@ -619,3 +624,67 @@ def test_large_batch_and_noncontiguous_inputs(dev):
                                   torch.zeros(Rs, 1), torch.full((Rs, 1), 6.0), training=False)
     assert max_abs(out["mid_rgb_fine"][-Rs:].cpu(), ref["mid_rgb_fine"]) <= TOL
     assert max_abs(out["accumulation_fine"][-Rs:].cpu(), ref["accumulation_fine"]) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------- §8(f): loss + optimiser
+def test_fused_loss_matches_torch_formulas(dev):
+    """get_loss_dict (model.py:346-430) through rsn_loss_forward_backward: values and gradients against the plain
+    torch formulas, including a zeroed (warm-up) coefficient."""
+    from reflect_sampling_nerf_amd.train_ops import LOSS_TERMS, fused_loss_dict
+
+    g = torch.Generator().manual_seed(5)
+    R, Sc, Sf = 37, 11, 19
+    mk = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    leaves = {"mid_rgb_coarse": mk(R, 3), "mid_rgb_fine": mk(R, 3), "mid_reflect_coarse": mk(R, 3),
+              "mid_reflect_fine": mk(R, 3), "pred_normals_coarse": mk(R, Sc, 3) - 0.5,
+              "pred_normals_fine": mk(R, Sf, 3) - 0.5, "n_dot_d_coarse": mk(R, Sc, 1) - 0.5,
+              "n_dot_d_fine": mk(R, Sf, 1) - 0.5}
+    consts = {"weights_coarse": mk(R, Sc, 1), "weights_fine": mk(R, Sf, 1), "normals_coarse": mk(R, Sc, 3) - 0.5,
+              "normals_fine": mk(R, Sf, 3) - 0.5}
+    image = mk(R, 3)
+    coef = {k: c for k, c in zip(LOSS_TERMS, (1.0, 1.0, 1.0, 1.0, 3e-5, 0.0, 1e-2, 1e-1))}
+    ref_in = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+    o = {**ref_in, **consts}
+    ref = {
+        "loss_mid_coarse": torch.nn.functional.mse_loss(image, o["mid_rgb_coarse"]),
+        "loss_mid_fine": torch.nn.functional.mse_loss(image, o["mid_rgb_fine"]),
+        "loss_reflect_mid_coarse": torch.nn.functional.mse_loss(image, o["mid_reflect_coarse"]),
+        "loss_reflect_mid_fine": torch.nn.functional.mse_loss(image, o["mid_reflect_fine"]),
+        "predicted_normal_loss_coarse": torch.sum(o["weights_coarse"] * torch.sum((o["normals_coarse"] - o["pred_normals_coarse"]) ** 2, dim=-1, keepdim=True)),
+        "predicted_normal_loss_fine": torch.sum(o["weights_fine"] * torch.sum((o["normals_fine"] - o["pred_normals_fine"]) ** 2, dim=-1, keepdim=True)),
+        "orientation_loss_coarse": torch.sum(o["weights_coarse"] * torch.max(torch.zeros_like(o["n_dot_d_coarse"]), o["n_dot_d_coarse"]) ** 2),
+        "orientation_loss_fine": torch.sum(o["weights_fine"] * torch.max(torch.zeros_like(o["n_dot_d_fine"]), o["n_dot_d_fine"]) ** 2),
+    }
+    ref = {k: v * coef[k] for k, v in ref.items()}
+    sum(ref.values()).backward()
+    gpu_in = {k: v.clone().to(dev).requires_grad_(True) for k, v in leaves.items()}
+    out = fused_loss_dict({**gpu_in, **{k: v.to(dev) for k, v in consts.items()}}, image.to(dev), coef)
+    assert list(out.keys()) == list(LOSS_TERMS)
+    for k in LOSS_TERMS:
+        assert abs(float(out[k]) - float(ref[k])) <= 1e-5 * max(1.0, abs(float(ref[k]))), k
+    sum(out.values()).backward()
+    for k in leaves:
+        assert max_abs(gpu_in[k].grad.cpu(), ref_in[k].grad) <= 1e-6, k
+
+
+def test_fused_radam_matches_torch_optim(dev):
+    """rsn_radam_step against torch.optim.RAdam (lr 1e-3, eps 1e-15: reference config.py:50-53) over 12 steps, i.e.
+    across the rho_t > 5 switch (step 6), with a parameter that never receives a gradient."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(17, 9), (33,), (256, 99), (1,)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes] + [torch.nn.Parameter(torch.ones(5))]
+    gpu_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    opt_ref = torch.optim.RAdam(ref_p, lr=1e-3, eps=1e-15)
+    opt_gpu = pkg.FusedRAdam(gpu_p, lr=1e-3, eps=1e-15)
+    for step in range(12):
+        for pr, pg in zip(ref_p[:-1], gpu_p[:-1]):
+            gr = torch.randn(*pr.shape, generator=g) * (0.1 + step)
+            pr.grad, pg.grad = gr.clone(), gr.clone().to(dev)
+        v_before = gpu_p[0]._version
+        opt_ref.step()
+        opt_gpu.step()
+        assert gpu_p[0]._version > v_before  # consumers keyed on Tensor._version (packed weights) see the update
+    for pr, pg in zip(ref_p, gpu_p):
+        assert max_abs(pg.detach().cpu(), pr.detach()) <= 2e-6
+    assert pkg.exponential_decay_lr(0) == 1e-3 and abs(pkg.exponential_decay_lr(50000) - 1e-4) < 1e-12
+    assert abs(pkg.exponential_decay_lr(25000) - (1e-3 * 1e-4) ** 0.5) < 1e-12
