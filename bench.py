@@ -49,6 +49,7 @@ def parse():
                     help="matrix-core arithmetic of the eval field kernel: f32 = exact fp32 MFMA (default); bf16x6 = "
                          "fp32 emulation by 3-way bf16 splits (fp32-equivalent results); bf16x3 = reduced precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -87,6 +88,59 @@ def cpu_baseline(args):
         "sample": f"{Rc} rays x {args.samples} samples, same field ({args.layers}x{args.width}) and level, "
                   f"median of {len(times)} runs, oracle/cpu_ref.render_level (eager PyTorch fp32)",
     }
+
+
+def train_leg(pkg, args, dev, rank, world, dist, share):
+    """Secondary measurement of the default run: BASELINE configs[2]/[4], one full training step per rank (forward,
+    twelve loss terms, backward, ONE flat gradient all-reduce over RCCL when N > 1, fused RAdam), timed with the same
+    barrier + synchronize + max-over-ranks bracket.  Reported as `train_step` next to the headline; never `value`."""
+    from oracle.cpu_ref import synthetic_rays  # input generator only
+    from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, train_step
+
+    R = args.rays
+    torch.manual_seed(0)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=64, num_importance_samples=128,
+                                            base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised
+    model.to(dev).train()
+    o, d, pa = synthetic_rays(R, seed=rank)
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.reshape(R, 1).to(dev),
+                       nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
+    params = model.get_param_groups()["fields"]
+    optimizer = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15, lr_final=1e-4, max_steps=50000)
+    reducer = FlatGradAllReduce(params) if world > 1 else None
+    batch = {"image": torch.rand(R, 3, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)}
+    steps, warmup, it = min(args.steps, 20), min(max(args.warmup, 1), 3), 100  # past the 50-step loss warm-up
+    for _ in range(warmup):
+        train_step(model, rb, batch, optimizer, reducer, it)
+        it += 1
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_step(model, rb, batch, optimizer, reducer, it)
+        it += 1
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    with torch.no_grad():
+        model.eval()
+        mask_frac = float(model(rb)["mask"].float().mean())
+    return {"value": world * R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "warmup": warmup, "n_gpus": world, "dtype": "f32", "loss": float(loss), "reflect_ray_fraction": mask_frac,
+            "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect (64 + 64) per rank, forward + "
+                        "12-term loss + backward + %s + fused RAdam" %
+                        (R, "one flat 618513-float gradient all-reduce (RCCL)" if world > 1 else "no collective (N=1)")}
 
 
 def main():
@@ -215,6 +269,7 @@ def main():
         with torch.no_grad():
             model.eval()
             state["mask_frac"] = float(model(rb)["mask"].float().mean())
+    line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * R * args.steps / elapsed
@@ -284,6 +339,36 @@ def main():
             line["alt_mma_modes"] = state["alt"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
+    if args.workload == "level" and args.mma == "f32" and not args.no_train_leg:
+        # Secondary leg, every rank.  It must never cost the headline line: a watchdog prints the line without it
+        # and ends the process if the leg does not come back (a rank lost inside the gradient all-reduce).
+        import threading
+
+        finished = threading.Event()
+
+        def watchdog():
+            if finished.wait(timeout=240.0):
+                return
+            if rank == 0:
+                line["train_step"] = {"error": "training leg did not finish within 240 s; headline unaffected"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            res = train_leg(pkg, args, dev, rank, world, dist, share)
+        except Exception as exc:
+            res = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if world > 1:  # the other ranks may be waiting in a collective: leave it to their watchdogs
+                finished.set()
+                if rank == 0:
+                    line["train_step"] = res
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        finished.set()
+        if rank == 0:
+            line["train_step"] = res
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

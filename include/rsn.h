@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 7
+#define RSN_ABI_VERSION 8
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -300,6 +300,14 @@ int rsn_composite_backward(int32_t n_rays, const int32_t* n_dev, int32_t n_sampl
  * accumulators.  dW / db are ACCUMULATED (the caller zeroes them once per step); row-major, leading dims in floats. */
 int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x, int32_t ld_x,
                     int32_t k_in, const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream);
+
+/* rsn_weight_grad_multi: the same reduction over n_segments (<= 8) point sets in ONE launch -- segment s holds
+ * n_points[s] rows of dy[s] / x[s] (HOST arrays of device pointers; common leading dimensions).  The five field
+ * evaluations of one training step (model.py:146-292) share their weights, so the per-launch cost (the atomic flush
+ * of the stationary output tile) is paid once per layer instead of once per layer and evaluation. */
+int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
+                          int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map,
+                          float* dw, int32_t ld_dw, float* db, void* stream);
 
 /* rsn_colsum: out[c] (+)= sum_r x[r*ld + c], c < n_cols (bias gradients = column sums of dY). */
 int rsn_colsum(int64_t n_rows, int32_t n_cols, int32_t ld, const float* x, float* out, int32_t accumulate,

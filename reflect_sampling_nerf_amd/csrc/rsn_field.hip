@@ -162,6 +162,30 @@ __device__ __forceinline__ void sh34_attenuated(float x, float y, float z, float
   sh[33] = 0.72892666017482986f * (x2 * re7 - y2 * im7) * e8;
 }
 
+// Optional per-phase cycle accounting (debug builds only: tools/phase_report.py compiles a second library with
+// -DRSN_PHASE_TIMERS).  Wave 0 of every workgroup sums shader-clock deltas per phase; never part of librsn_hip.so.
+#ifdef RSN_PHASE_TIMERS
+__device__ unsigned long long rsn_phase_cycles[16];
+#define RSN_T(i)                                \
+  do {                                          \
+    __builtin_amdgcn_sched_barrier(0);          \
+    const long long tn_ = clock64();            \
+    tacc[i] += tn_ - tlast;                     \
+    tlast = tn_;                                \
+    __builtin_amdgcn_sched_barrier(0);          \
+  } while (0)
+extern "C" int rsn_debug_phase_cycles(unsigned long long* out16, int reset) {
+  if (out16) RSN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(rsn_phase_cycles), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    RSN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rsn_phase_cycles), z, sizeof(z)));
+  }
+  return RSN_OK;
+}
+#else
+#define RSN_T(i)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <int NB, bool TRAIN, int MODE>
 __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
@@ -185,17 +209,24 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
   const long long n_points = (long long)n_rays * a.S;
   const long long n_tiles = (n_points + 127) / 128;
   const float* __restrict__ pk = a.packed;
+#ifdef RSN_PHASE_TIMERS
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#endif
 
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long p0 = tile * 128 + wid * 32;
     if (p0 >= n_points) continue;  // wave-uniform; waves never synchronise with each other
+    RSN_T(11);
     const long long p = p0 + m;
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
 
     float mc[3] = {0.0f, 0.0f, 0.0f}, vc[3] = {0.0f, 0.0f, 0.0f}, vd[3] = {0.0f, 0.0f, 0.0f};
     bool has_cov = true, has_dir = true;
+    float4 wbh[NB + 1];  // first weight fragment of the bottleneck+heads GEMM
     if (a.mode == RSN_MODE_EMB) {
+      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, lane);
       // granular Field API: heads / mid MLP on a caller-supplied embedding (field.py:139-186)
       has_dir = a.view_dirs != nullptr;
 #pragma unroll
@@ -283,17 +314,27 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       for (int it = 0; it < RSN_ENC_ITS; ++it) *reinterpret_cast<float4*>(row + it * 8 + 4 * h) = X[it * 64];
     }
 
+    RSN_T(0);
     // ---------------- trunk -----------------
     {
       f32x16 acc[NB];
+      float4 wpre[NB];  // first weight fragment of the next GEMM, fetched ahead of the epilogue in front of it
+      pre_mode<MODE, NB>(wpre, pk + a.L.w_enc0, lane);
       init_acc<NB>(acc, pk + a.L.b[0], h);
-      gemm_mode<MODE, NB>(acc, pk + a.L.w_enc0, pk + a.L.h_enc0, X, RSN_ENC_ITS, lane);
-      store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + pc * W : nullptr, h);
+      RSN_T(1);
+      gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc0, pk + a.L.h_enc0, X, RSN_ENC_ITS, lane);
+      RSN_T(2);
 #pragma unroll 1
       for (int l = 1; l < a.num_layers; ++l) {
-        init_acc<NB>(acc, pk + a.L.b[l], h);
-        gemm_mode<MODE, NB>(acc, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, lane);
+        pre_mode<MODE, NB>(wpre, pk + a.L.w_x[l], lane);
+        // ReLU between layers; the accumulators restart from layer l's bias
+        store_act_init<NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (l - 1) * a.act_stride + pc * W : nullptr,
+                                 h, pk + a.L.b[l]);
+        RSN_T(3);
+        gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, lane);
+        RSN_T(4);
         if (l == a.skip_layer) {
+          pre_mode<MODE, NB>(wpre, pk + a.L.w_enc_skip, lane);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             X[it * 64] = make_float4(st0[4 * it], st0[4 * it + 1], st0[4 * it + 2], st0[4 * it + 3]);
@@ -302,11 +343,14 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           }
           X[12 * 64] = st3;
           if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          gemm_mode<MODE, NB>(acc, pk + a.L.w_enc_skip, pk + a.L.h_enc_skip, X, RSN_ENC_ITS, lane);
+          gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc_skip, pk + a.L.h_enc_skip, X, RSN_ENC_ITS, lane);
+          RSN_T(2);
         }
-        // ReLU between layers and out_activation=ReLU
-        store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + l * a.act_stride + pc * W : nullptr, h);
       }
+      // out_activation = ReLU
+      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, lane);
+      store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (a.num_layers - 1) * a.act_stride + pc * W : nullptr, h);
+      RSN_T(3);
     }
     }  // mode != RSN_MODE_EMB
     if (a.embedding && valid) {
@@ -317,10 +361,14 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
 
     // ---------------- bottleneck + heads (one GEMM, N = W + 32) -----------------
     float dcol[3], tcol[3], rho;
+    float4 wmid[4];  // first weight fragment of mlp_mid's SH part
     {
       f32x16 acc[NB + 1];
       init_acc<NB + 1>(acc, pk + a.L.b_bh, h);
-      gemm_mode<MODE, NB + 1>(acc, pk + a.L.w_bh, pk + a.L.h_bh, X, NB * 4, lane);
+      RSN_T(1);
+      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + a.L.w_bh, pk + a.L.h_bh, X, NB * 4, lane);
+      RSN_T(5);
+      pre_mode<MODE, 4>(wmid, pk + a.L.w_mid_sh, lane);
       const float r0 = acc[NB][0], r1 = acc[NB][1], r2 = acc[NB][2], r3 = acc[NB][3];
       const float r4 = acc[NB][4], r5 = acc[NB][5], r6 = acc[NB][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
@@ -385,18 +433,29 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       }
     }
 
+    RSN_T(6);
     // ---------------- mlp_mid + RGB head -----------------
+    float4 wrgb[1];
     {
       f32x16 accm[4];
       init_acc<4>(accm, pk + a.L.b_mid, h);
-      gemm_mode<MODE, 4>(accm, pk + a.L.w_mid_sh, pk + a.L.h_mid_sh, AUX, RSN_SH_ITS, lane);
-      gemm_mode<MODE, 4>(accm, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, lane);
+      RSN_T(1);
+      float4 wmx[4];
+      pre_mode<MODE, 4>(wmx, pk + a.L.w_mid_x, lane);
+      gemm_mode_run<MODE, 4>(accm, wmid, pk + a.L.w_mid_sh, pk + a.L.h_mid_sh, AUX, RSN_SH_ITS, lane);
+      RSN_T(7);
+      gemm_mode_run<MODE, 4>(accm, wmx, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, lane);
+      RSN_T(8);
+      pre_mode<MODE, 1>(wrgb, pk + a.L.w_rgb, lane);
       store_act<4, 4, true>(accm, X, (TRAIN && a.saved.hid && valid) ? a.saved.hid + pc * 128 : nullptr, h);
+      RSN_T(3);
     }
     {
       f32x16 accr[1];
       init_acc<1>(accr, pk + a.L.b_rgb, h);
-      gemm_mode<MODE, 1>(accr, pk + a.L.w_rgb, pk + a.L.h_rgb, X, 16, lane);
+      RSN_T(1);
+      gemm_mode_run<MODE, 1>(accr, wrgb, pk + a.L.w_rgb, pk + a.L.h_rgb, X, 16, lane);
+      RSN_T(9);
       if (h == 1 && valid) {
         const float m0 = sigmoid_f(accr[0][0]);
         const float m1 = sigmoid_f(accr[0][1]);
@@ -414,6 +473,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       }
     }
 
+    RSN_T(10);
     // ---------------- training: analytic normals = -normalize(d raw_density / d contracted mean) -----------------
     // (reflect_sampling_nerf_field.py:125-127,146-147 -> nerfstudio Field.get_normals).  A dX-only sweep back
     // through the trunk: seed = density-head row masked by the embedding's ReLU, then W_l^T GEMMs masked by the
@@ -477,6 +537,13 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       }
     }
   }
+#ifdef RSN_PHASE_TIMERS
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) atomicAdd(&rsn_phase_cycles[i], (unsigned long long)tacc[i]);
+    atomicAdd(&rsn_phase_cycles[15], 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

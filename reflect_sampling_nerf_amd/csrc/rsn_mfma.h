@@ -62,35 +62,65 @@ __device__ __forceinline__ void mma4(f32x16 (&acc)[NBO], const float4 (&w)[NBO],
 }
 
 // wseg: packed segment base (global), xl: this lane's slot of the LDS slab (float4 units, stride 64 per it).
-// sched_barrier(0) pins the software pipeline: the loads of K-iteration it+1 are issued BEFORE the 32 MFMAs
-// of iteration it (hipcc otherwise sinks them to just ahead of their first use, leaving ~500 cycles of cover
-// for an L2 round trip instead of 2048).
+// Software pipeline: the loads of K-iteration it+1 are issued while the 32 MFMAs of iteration it run, one load
+// after each of the first NBO MFMAs (sched_group_barrier pattern), so every load has a full iteration (2048 MFMA
+// cycles) of cover; hipcc on its own sinks the loads to just ahead of their first use.
+// Measured with tools/phase_report.py (BASELINE config 2): the trunk K loops run at 93.5 % of the MFMA issue rate;
+// with the weight stream removed they reach 98.8 %.  About half of that gap remains when every load hits L1, and
+// neither a prefetch distance of two iterations (three fragment buffers) nor the position of the loads inside the
+// iteration changes it: it is a per-load cost (register-file write traffic beside the MFMA operand reads, L2
+// service of the same lines to all CUs of an XCD), not exposed latency.
 template <int NBO>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl, int n_it,
-                                     int lane) {
+__device__ __forceinline__ void interleave_loads() {
+#pragma unroll
+  for (int g = 0; g < NBO; ++g) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the LDS read of the activations
+}
+
+// First weight fragment of a segment: issued by the caller ahead of the epilogue in front of the GEMM so that its L2
+// round trip hides under that epilogue.
+template <int NBO>
+__device__ __forceinline__ void pre_w(float4 (&wa)[NBO], const float* __restrict__ wseg, int lane) {
+  load_w<NBO>(wa, reinterpret_cast<const float4*>(wseg) + lane, 0);
+}
+
+template <int NBO>
+__device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ wseg,
+                                          const float4* xl, int n_it, int lane) {
   const float4* __restrict__ wp = reinterpret_cast<const float4*>(wseg) + lane;
-  float4 wa[NBO], wb[NBO];
+  float4 wb[NBO];
   float4 ba, bb;
-  load_w<NBO>(wa, wp, 0);
   ba = xl[0];
   int it = 0;
 #pragma unroll 1
   for (; it + 1 < n_it; it += 2) {
     load_w<NBO>(wb, wp, it + 1);
     bb = xl[(it + 1) * 64];
-    __builtin_amdgcn_sched_barrier(0);
     mma4<NBO>(acc, wa, ba);
+    interleave_loads<NBO>();
     __builtin_amdgcn_sched_barrier(0);
     {  // unconditional prefetch with a clamped index: one control path => exact vmcnt counts
       const int in = (it + 2 < n_it) ? it + 2 : n_it - 1;
       load_w<NBO>(wa, wp, in);
       ba = xl[in * 64];
     }
-    __builtin_amdgcn_sched_barrier(0);
     mma4<NBO>(acc, wb, bb);
+    interleave_loads<NBO>();
     __builtin_amdgcn_sched_barrier(0);
   }
   if (it < n_it) mma4<NBO>(acc, wa, ba);
+}
+
+template <int NBO>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl, int n_it,
+                                     int lane) {
+  float4 wa[NBO];
+  pre_w<NBO>(wa, wseg, lane);
+  gemm_run<NBO>(acc, wa, wseg, xl, n_it, lane);
 }
 
 // acc[nb][4q+j] = bias[nb*32 + 8q + 4h + j]: the accumulators start from the bias (what torch's addmm does),
@@ -221,6 +251,23 @@ __device__ __forceinline__ void gemm_mode(f32x16 (&acc)[NBO], const float* __res
   }
 }
 
+// the same with the first fp32 weight fragment fetched early by the caller (pre_mode ... gemm_mode_run); the
+// split-bf16 loops fetch their own first fragment (pre_mode is a no-op for them)
+template <int MODE, int NBO>
+__device__ __forceinline__ void pre_mode(float4 (&wa)[NBO], const float* __restrict__ w32, int lane) {
+  if (MODE == 0) pre_w<NBO>(wa, w32, lane);
+}
+
+template <int MODE, int NBO>
+__device__ __forceinline__ void gemm_mode_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ w32,
+                                              const float* __restrict__ w16, const float4* xl, int n_it, int lane) {
+  if (MODE == 0) {
+    gemm_run<NBO>(acc, wa, w32, xl, n_it, lane);
+  } else {
+    gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
+  }
+}
+
 template <int NBO>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
 #pragma unroll
@@ -247,6 +294,32 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
       }
       xl[(nb * 4 + q) * 64] = v;
       if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+    }
+}
+
+// store_act of one layer fused with init_acc of the next (same NBO): block by block the accumulators are read out and
+// immediately re-loaded with the next layer's bias, so the bias round trip hides under the rest of the epilogue.
+template <int NBO, bool RELU>
+__device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, float* save, int h,
+                                               const float* __restrict__ bias) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
+      if (RELU) {
+        v.x = relu_f(v.x);
+        v.y = relu_f(v.y);
+        v.z = relu_f(v.z);
+        v.w = relu_f(v.w);
+      }
+      xl[(nb * 4 + q) * 64] = v;
+      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+      const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
+      acc[nb][4 * q + 0] = bv.x;
+      acc[nb][4 * q + 1] = bv.y;
+      acc[nb][4 * q + 2] = bv.z;
+      acc[nb][4 * q + 3] = bv.w;
     }
 }
 

@@ -3,32 +3,47 @@
 // A reduction GEMM over ALL sample points (M ~ 1e5..1e6) with a small output (<= 256 x 256): the opposite
 // shape of the forward GEMMs, and one the BLAS library serves poorly (hipBLASLt picks 32x64 tiles: 36 ms per
 // training step at BASELINE config 3).  Here the OUTPUT is stationary: a 4-wave workgroup keeps the whole
-// dW tile in MFMA accumulators (wave w owns output rows [64w, 64w+64) x all input columns = 16 blocks of
-// 32x32 = 256 accumulator registers) and streams its chunk of points once.  For v_mfma_f32_32x32x2_f32 with
-// A = dY^T and B = X the two fragments are simply "one float per lane from row m0 + h": lane (i, h) reads
-// dY[m0+h][n0+i] and X[m0+h][k0+i] straight from the row-major buffers (32 consecutive floats per half-wave:
-// two full 128-B segments per load), so no LDS and no barriers are needed.  The bias gradient is the running sum
-// of the A fragments.  Each workgroup flushes its partial tile once with fp32 atomics (two 128-B row segments
-// per wave instruction: the full-rate shape, MI355X_MICROARCH.md "Global float atomics").
+// dW tile in MFMA accumulators (wave w owns 64 output rows x all input columns = 16 blocks of 32x32 = 256
+// accumulator registers) and streams its chunk of points once.  For v_mfma_f32_32x32x2_f32 with A = dY^T and
+// B = X a fragment is "one float per lane from row m0 + h", straight from the row-major buffers: no LDS and no
+// barriers in the main loop.  Which output row / input column a lane's fragment element stands for is a free
+// permutation, so lane i takes the NKB CONSECUTIVE columns i*NKB .. i*NKB+NKB-1 (block kb = element kb) and
+// the two consecutive rows 2i, 2i+1: one row of X is two global_load_dwordx4 per lane (a half-wave reads
+// 1 KiB contiguous) and dY one dwordx2 -- 3 load instructions per 16 MFMAs instead of 10 (every vector-memory
+// instruction costs the matrix pipe a few cycles, see rsn_mfma.h).  The permutation is undone once, at the
+// flush, through a wave-private 2 KiB LDS tile, so that the fp32 atomics keep the full-rate shape (two 128-B
+// row segments per wave instruction, MI355X_MICROARCH.md "Global float atomics").
+//
+// One launch can reduce over several point segments (the five field evaluations of a training step share
+// their weights): the per-launch costs -- a 67 MB atomic flush for a 256 x 256 output on 256 workgroups,
+// ~50 us -- are paid once per layer instead of once per layer and level.
 //
 // MFMA-bound: 2 * N * n_out * k_in FLOP; HBM reads N * (n_out + k_in) * 4 B (each operand once per workgroup).
 #include "rsn_mfma.h"
 
+#define WG_MAX_SEG 8
+
 struct WGradArgs {
-  long long n_points;
-  long long chunk;        // points per workgroup (multiple of 8)
-  const float* dy;        // [N, ld_dy]
-  const float* x;         // [N, ld_x]
+  int n_seg;
+  long long seg_begin[WG_MAX_SEG + 1];  // prefix sums of the segment lengths (points)
+  const float* dy[WG_MAX_SEG];          // [n_s, ld_dy]
+  const float* x[WG_MAX_SEG];           // [n_s, ld_x]
   int ld_dy, ld_x, n_out, k_in, ld_dw;
-  const int* col_map;     // optional: packed column k -> destination column (or -1)
-  float* dw;              // [n_out, ld_dw], accumulated
-  float* db;              // [n_out] or NULL, accumulated
+  const int* col_map;  // optional: packed column k -> destination column (or -1)
+  float* dw;           // [n_out, ld_dw], accumulated
+  float* db;           // [n_out] or NULL, accumulated
 };
 
+#ifndef WG_PAIRS
 #define WG_PAIRS 4  // point pairs (MFMA K-steps) per software-pipeline stage
+#endif
 
-template <int NKB>  // input-column blocks of 32 held per wave (8 covers k_in <= 256)
+// NKB: input-column blocks of 32 held per wave (8 covers k_in <= 256).
+// XV: lane i owns columns i*NKB.. (vector loads of X);  else column kb*32+i (scalar loads, any k_in / alignment).
+// DV: lane i owns rows 2i, 2i+1 of the wave's 64 (dwordx2 loads of dY); else rows t*32+i.
+template <int NKB, bool XV, bool DV>
 __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
+  __shared__ float tr[4][2][NKB * 32];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar loop control
   const int i = lane & 31, h = lane >> 5;
@@ -39,13 +54,16 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   const int nsub = 4 / P;
   const int nb0 = (wid % P) * 2;  // this wave's two 32-row output blocks
   const int sub = wid / P;
-  const long long wg_begin = (long long)blockIdx.x * a.chunk;
-  const long long sub_chunk = a.chunk / nsub;  // chunk is a multiple of 16
-  const long long m_begin = wg_begin + sub * sub_chunk;
-  long long m_end = m_begin + sub_chunk;
-  if (m_end > a.n_points) m_end = a.n_points;
-  if (m_begin >= a.n_points) return;
-  const bool t1_live = (nb0 + 1) * 32 < a.n_out;  // wave-uniform: second row block holds live rows
+  // Pipeline stages (2*WG_PAIRS consecutive points) are dealt round-robin to the G = gridDim * nsub wave slots: at any
+  // moment the chip reads one contiguous window of G stages (no equal-offset streams from 1 MiB-spaced bases), and
+  // the split is even for any number and size of segments.
+  // Measured (tools/wgrad_report.py, 256 x 256 output): 281 us per 262,144 points = 122 TFLOP/s in the streaming
+  // part, 246 us with the loads removed: the four waves of a workgroup each fetch the whole X row (L1 only partly
+  // dedups them), ~10 B/cycle/CU of fill traffic, the per-CU streaming limit.  Sharing X through LDS would halve
+  // that; not done yet.
+  const long long G = (long long)gridDim.x * nsub;
+  const long long g = (long long)blockIdx.x * nsub + sub;
+  const bool t1_live = DV || (nb0 + 1) * 32 < a.n_out;  // wave-uniform: second row block holds live rows
 
   f32x16 acc[2][NKB];
 #pragma unroll
@@ -56,51 +74,70 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
       for (int r = 0; r < 16; ++r) acc[t][kb][r] = 0.0f;
   float bsum[2] = {0.0f, 0.0f};
 
-  // Lane columns are clamped into range instead of masked: a lane whose output row / input column does not exist
-  // works on a duplicate of the last valid one and its results are never flushed.  Nothing in the main loop
+  // Lane rows / columns are clamped into range instead of masked: a lane whose output row / input column does
+  // not exist works on a duplicate of a valid one and its results are never flushed.  Nothing in the main loop
   // touches a loaded value before the MFMAs do, so the loads of stage s+1 stay in flight under the MFMAs of stage s.
   int cdy[2], cx[NKB];
+  if (DV) {
+    const int n_even = a.n_out + (a.n_out & 1);  // the host checked ld_dy >= n_even
+    const int c = nb0 * 32 + 2 * i;
+    cdy[0] = c < n_even - 2 ? c : n_even - 2;
+    cdy[1] = cdy[0] + 1;
+  } else {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int c = (nb0 + t) * 32 + i;
-    cdy[t] = c < a.n_out ? c : a.n_out - 1;
+    for (int t = 0; t < 2; ++t) {
+      const int c = (nb0 + t) * 32 + i;
+      cdy[t] = c < a.n_out ? c : a.n_out - 1;
+    }
   }
+  if (XV) {
+    const int c = i * NKB;  // the host checked k_in % NKB == 0
+    cx[0] = c < a.k_in - NKB ? c : a.k_in - NKB;
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb) {
-    const int c = kb * 32 + i;
-    cx[kb] = c < a.k_in ? c : a.k_in - 1;
+    for (int kb = 1; kb < NKB; ++kb) cx[kb] = cx[0] + kb;
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int c = kb * 32 + i;
+      cx[kb] = c < a.k_in ? c : a.k_in - 1;
+    }
   }
-  const float* __restrict__ dyp = a.dy;
-  const float* __restrict__ xp = a.x;
 
   float fa[2][WG_PAIRS][2], fb[2][WG_PAIRS][NKB];  // [buffer][pair][block]
+  const float* __restrict__ dyp = nullptr;
+  const float* __restrict__ xp = nullptr;
 
-  auto load_stage = [&](int buf, long long m0) {  // all 2*WG_PAIRS points of the stage are in range
-#pragma unroll
-    for (int p = 0; p < WG_PAIRS; ++p) {
-      const long long m = m0 + 2 * p + h;
-      const float* __restrict__ dr = dyp + m * a.ld_dy;
-      const float* __restrict__ xr = xp + m * a.ld_x;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) fa[buf][p][t] = dr[cdy[t]];
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) fb[buf][p][kb] = xr[cx[kb]];
-    }
-  };
-  auto load_stage_tail = [&](int buf, long long m0) {  // points beyond m_end contribute zeros
-#pragma unroll
-    for (int p = 0; p < WG_PAIRS; ++p) {
-      const long long m = m0 + 2 * p + h;
-      const bool in = m < m_end;
-      const long long mc = in ? m : m_begin;
+  auto load_row = [&](int buf, int p, long long m, bool in) {
+    const float* __restrict__ dr = dyp + m * a.ld_dy;
+    const float* __restrict__ xr = xp + m * a.ld_x;
+    if (DV) {
+      const float2 v = *reinterpret_cast<const float2*>(dr + cdy[0]);
+      fa[buf][p][0] = in ? v.x : 0.0f;
+      fa[buf][p][1] = in ? v.y : 0.0f;
+    } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const float v = dyp[mc * a.ld_dy + cdy[t]];
+        const float v = dr[cdy[t]];
         fa[buf][p][t] = in ? v : 0.0f;
       }
+    }
+    if (XV && NKB >= 4) {
+#pragma unroll
+      for (int q = 0; q < NKB / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + cx[0] + 4 * q);
+        fb[buf][p][4 * q + 0] = in ? v.x : 0.0f;
+        fb[buf][p][4 * q + 1] = in ? v.y : 0.0f;
+        fb[buf][p][4 * q + 2] = in ? v.z : 0.0f;
+        fb[buf][p][4 * q + 3] = in ? v.w : 0.0f;
+      }
+    } else if (XV) {
+      const float2 v = *reinterpret_cast<const float2*>(xr + cx[0]);
+      fb[buf][p][0] = in ? v.x : 0.0f;
+      fb[buf][p][1] = in ? v.y : 0.0f;
+    } else {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
-        const float v = xp[mc * a.ld_x + cx[kb]];
+        const float v = xr[cx[kb]];
         fb[buf][p][kb] = in ? v : 0.0f;
       }
     }
@@ -119,60 +156,104 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     }
   };
 
-  const long long step = 2 * WG_PAIRS;
-  const long long n_full = (m_end - m_begin) / step;  // stages with every point in range
-  if (n_full > 0) load_stage(0, m_begin);
-#pragma unroll 1
-  for (long long sidx = 0; sidx < n_full; sidx += 2) {
-    const long long m0 = m_begin + sidx * step;
-    if (sidx + 1 < n_full) load_stage(1, m0 + step);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_stage(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (sidx + 2 < n_full) load_stage(0, m0 + 2 * step);
-    __builtin_amdgcn_sched_barrier(0);
-    if (sidx + 1 < n_full) mma_stage(1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (m_begin + n_full * step < m_end) {
-    load_stage_tail(0, m_begin + n_full * step);
-    mma_stage(0);
-  }
+  auto interleave_stage = [&]() {
+#pragma unroll
+    for (int g = 0; g < WG_PAIRS * 4; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x026, 2, 0);  // up to 2 of VALU / SALU / VMEM read
+    }
+  };
 
-  // flush: C/D layout col = lane&31 (input column), row = (r&3) + 8*(r>>2) + 4*h (output row)
+  const long long step = 2 * WG_PAIRS;
+  long long vprefix = 0;  // stages (full and tail) of the segments in front of this one
+  bool any = false;
+#pragma unroll 1
+  for (int s = 0; s < a.n_seg; ++s) {
+    const long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
+    const long long n_full = n_s / step;  // stages with every point in range
+    const long long rem = n_s - n_full * step;
+    const long long first = ((g - vprefix) % G + G) % G;  // this slot's first stage of the segment
+    const long long cnt = first < n_full ? (n_full - first + G - 1) / G : 0;
+    dyp = a.dy[s];
+    xp = a.x[s];
+    const long long gs = G * step;
+    if (cnt > 0) {
+      any = true;
+#pragma unroll
+      for (int p = 0; p < WG_PAIRS; ++p) load_row(0, p, first * step + 2 * p + h, true);
+    }
+    long long j = 0;
+#pragma unroll 1
+    for (; j + 1 < cnt; j += 2) {
+      const long long m0 = (first + j * G) * step;
+      // the next stage's loads (and their address arithmetic) are slotted between this stage's MFMAs: issued as a
+      // block between two MFMA bursts they left the matrix pipe idle for ~10 % of the loop.  Straight-line body
+      // (the prefetch index is clamped, not branched on) so that the scheduler can interleave.
+#pragma unroll
+      for (int p = 0; p < WG_PAIRS; ++p) load_row(1, p, m0 + gs + 2 * p + h, true);
+      mma_stage(0);
+      interleave_stage();
+      __builtin_amdgcn_sched_barrier(0);
+      const long long m2 = (j + 2 < cnt) ? m0 + 2 * gs : m0 + gs;
+#pragma unroll
+      for (int p = 0; p < WG_PAIRS; ++p) load_row(0, p, m2 + 2 * p + h, true);
+      mma_stage(1);
+      interleave_stage();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (j < cnt) mma_stage(0);
+    if (rem > 0 && (vprefix + n_full) % G == g) {  // the segment's tail stage: points beyond n_s contribute zeros
+      any = true;
+#pragma unroll
+      for (int p = 0; p < WG_PAIRS; ++p) {
+        const long long m = n_full * step + 2 * p + h;
+        const bool in = m < n_s;
+        load_row(0, p, in ? m : 0, in);
+      }
+      mma_stage(0);
+    }
+    vprefix += n_full + (rem > 0 ? 1 : 0);
+  }
+  if (!any) return;  // wave-uniform: nothing accumulated, nothing to flush
+
+  // flush: C/D layout col = lane&31 (input-column slot), row = (r&3) + 8*(r>>2) + 4*h (output-row slot).  The
+  // wave-private LDS tile turns "lane i holds columns i*NKB+kb" back into "lane i holds column kb*32+i" so that one
+  // atomic wave-instruction covers two contiguous 128-B row segments.
+  float* trw = &tr[wid][h][0];
+  // destination columns first: a load between two atomics would wait (vmcnt counts both) for the atomic in front of it
+  int cdst[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int k = kb * 32 + i;
+    cdst[kb] = -1;
+    if (k < a.k_in) cdst[kb] = a.col_map ? a.col_map[k] : k;
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (t == 1 && !t1_live) continue;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      const int k = kb * 32 + i;
-      int c = -1;
-      if (k < a.k_in) c = a.col_map ? a.col_map[k] : k;
+    for (int r = 0; r < 16; ++r) {
+      const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int n = DV ? nb0 * 32 + 2 * slot + t : (nb0 + t) * 32 + slot;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = (nb0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (c >= 0 && n < a.n_out) atomicAdd(&a.dw[(long long)n * a.ld_dw + c], acc[t][kb][r]);
+      for (int kb = 0; kb < NKB; ++kb) trw[XV ? i * NKB + kb : kb * 32 + i] = acc[t][kb][r];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const float v = trw[kb * 32 + i];
+        if (cdst[kb] >= 0 && n < a.n_out) atomicAdd(&a.dw[(long long)n * a.ld_dw + cdst[kb]], v);
       }
     }
     if (a.db) {
       const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
-      const int n = (nb0 + t) * 32 + i;
+      const int n = DV ? nb0 * 32 + 2 * i + t : (nb0 + t) * 32 + i;
       if (h == 0 && n < a.n_out) atomicAdd(&a.db[n], v);
     }
   }
 }
 
-extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x,
-                               int32_t ld_x, int32_t k_in, const int32_t* col_map, float* dw, int32_t ld_dw,
-                               float* db, void* stream) {
-  RSN_REQUIRE(n_points >= 0 && n_out >= 1 && n_out <= 256 && k_in >= 1 && k_in <= 256, RSN_ERR_INVALID_ARGUMENT,
-              "n_points=%lld n_out=%d k_in=%d (outputs up to 256 x 256)", (long long)n_points, n_out, k_in);
-  RSN_REQUIRE(ld_dy >= n_out && ld_x >= k_in && ld_dw >= 1, RSN_ERR_INVALID_ARGUMENT, "leading dimensions too small");
-  if (n_points == 0) return RSN_OK;
-  RSN_REQUIRE(dy && x && dw, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
-  WGradArgs a;
-  a.n_points = n_points; a.dy = dy; a.x = x; a.ld_dy = ld_dy; a.ld_x = ld_x; a.n_out = n_out; a.k_in = k_in;
-  a.ld_dw = ld_dw; a.col_map = col_map; a.dw = dw; a.db = db;
+static int wgrad_launch(WGradArgs& a, void* stream) {
+  const long long total = a.seg_begin[a.n_seg];
+  if (total == 0) return RSN_OK;
   static int cached_cus = 0;
   if (cached_cus == 0) {
     int dev = 0, n = 0;
@@ -182,18 +263,82 @@ extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy,
     else
       cached_cus = 256;
   }
-  long long chunk = (n_points + cached_cus - 1) / cached_cus;
-  chunk = ((chunk + 15) / 16) * 16;
-  if (chunk < 64) chunk = 64;
-  a.chunk = chunk;
-  const long long grid = (n_points + chunk - 1) / chunk;
+  // grid: every workgroup pays one atomic flush of the output tile (chip-wide ~1.3 TB/s of added bytes) and the
+  // waves share the stages; T(G) = stages / (G * nsub) * t_stage + G * t_flush is smallest at G = sqrt(...)
+  const int nkb_ = a.k_in > 128 ? 8 : (a.k_in > 64 ? 4 : 2);
+  const int P = a.n_out <= 64 ? 1 : (a.n_out <= 128 ? 2 : 4);
+  const int nsub = 4 / P;
+  long long stages = 0;
+  for (int s = 0; s < a.n_seg; ++s) {
+    const long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
+    stages += (n_s + 2 * WG_PAIRS - 1) / (2 * WG_PAIRS);
+  }
+  const double t_stage = WG_PAIRS * (a.n_out > 32 ? 2 : 1) * nkb_ * 64 / 2.1e9;
+  const double t_flush = (double)a.n_out * a.k_in * 4.0 / 1.3e12 + 2e-8;
+  long long grid = (long long)(sqrt((double)stages * t_stage / (nsub * t_flush)) + 0.5);
+  if (grid > cached_cus) grid = cached_cus;
+  if (grid < 1) grid = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (k_in > 128)
-    hipLaunchKernelGGL(rsn_wgrad_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, a);
-  else if (k_in > 64)
-    hipLaunchKernelGGL(rsn_wgrad_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  const int nkb = a.k_in > 128 ? 8 : (a.k_in > 64 ? 4 : 2);
+  // vector-load variants need whole NKB-column groups and aligned rows; anything else takes the scalar-load path
+  bool xv = a.k_in % nkb == 0 && a.ld_x % (nkb >= 4 ? 4 : 2) == 0;
+  bool dv = a.n_out > 32 && a.ld_dy % 2 == 0 && a.ld_dy >= a.n_out + (a.n_out & 1);
+  for (int s = 0; s < a.n_seg; ++s) {
+    xv = xv && ((uintptr_t)a.x[s] % 16 == 0);
+    dv = dv && ((uintptr_t)a.dy[s] % 8 == 0);
+  }
+#define RSN_WG(NKBV)                                                                                           \
+  do {                                                                                                         \
+    if (xv && dv)                                                                                              \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a);     \
+    else if (xv)                                                                                               \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, false>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
+    else                                                                                                       \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, false, false>), dim3((unsigned)grid), dim3(256), 0, st, a);   \
+  } while (0)
+  if (nkb == 8)
+    RSN_WG(8);
+  else if (nkb == 4)
+    RSN_WG(4);
   else
-    hipLaunchKernelGGL(rsn_wgrad_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    RSN_WG(2);
+#undef RSN_WG
   RSN_HIP(hipGetLastError());
   return RSN_OK;
+}
+
+extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
+                                     int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
+                                     const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream) {
+  RSN_REQUIRE(n_segments >= 0 && n_segments <= WG_MAX_SEG, RSN_ERR_INVALID_ARGUMENT, "n_segments=%d (at most %d)",
+              n_segments, WG_MAX_SEG);
+  RSN_REQUIRE(n_out >= 1 && n_out <= 256 && k_in >= 1 && k_in <= 256, RSN_ERR_INVALID_ARGUMENT,
+              "n_out=%d k_in=%d (outputs up to 256 x 256)", n_out, k_in);
+  RSN_REQUIRE(ld_dy >= n_out && ld_x >= k_in && ld_dw >= 1, RSN_ERR_INVALID_ARGUMENT, "leading dimensions too small");
+  if (n_segments == 0) return RSN_OK;
+  RSN_REQUIRE(n_points && dy && x && dw, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  WGradArgs a = {};
+  a.seg_begin[0] = 0;
+  int ns = 0;
+  for (int s = 0; s < n_segments; ++s) {
+    RSN_REQUIRE(n_points[s] >= 0, RSN_ERR_INVALID_ARGUMENT, "n_points[%d]=%lld", s, (long long)n_points[s]);
+    if (n_points[s] == 0) continue;
+    RSN_REQUIRE(dy[s] && x[s], RSN_ERR_INVALID_ARGUMENT, "segment %d: a pointer is NULL", s);
+    a.dy[ns] = dy[s];
+    a.x[ns] = x[s];
+    a.seg_begin[ns + 1] = a.seg_begin[ns] + n_points[s];
+    ++ns;
+  }
+  a.n_seg = ns;
+  a.ld_dy = ld_dy; a.ld_x = ld_x; a.n_out = n_out; a.k_in = k_in;
+  a.ld_dw = ld_dw; a.col_map = col_map; a.dw = dw; a.db = db;
+  return wgrad_launch(a, stream);
+}
+
+extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x,
+                               int32_t ld_x, int32_t k_in, const int32_t* col_map, float* dw, int32_t ld_dw,
+                               float* db, void* stream) {
+  RSN_REQUIRE(n_points >= 0, RSN_ERR_INVALID_ARGUMENT, "n_points=%lld", (long long)n_points);
+  const int64_t n = n_points;
+  return rsn_weight_grad_multi(1, &n, &dy, ld_dy, n_out, &x, ld_x, k_in, col_map, dw, ld_dw, db, stream);
 }

@@ -133,35 +133,53 @@ class _GradAcc:
 def _wgrad(dy: Tensor, n_out: int, x: Tensor, k_in: int, dw: Tensor, dw_col0: int, db: Optional[Tensor],
            col_map: Optional[Tensor] = None):
     """dw[:, dw_col0 + (col_map[k] or k)] += dy[:, :n_out]^T x[:, :k_in];  db += column sums of dy."""
+    _wgrad_multi([(dy, x)], n_out, k_in, dw, dw_col0, db, col_map)
+
+
+def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Optional[Tensor],
+                 col_map: Optional[Tensor] = None):
+    """One rsn_weight_grad_multi launch: the reduction runs over the points of every (dy, x) segment (the field
+    evaluations of one step share their weights), so the per-launch flush is paid once per layer."""
     lib = _abi.load_library()
+    segs = [(dy, x) for dy, x in segs if dy.shape[0] > 0]
+    if not segs:
+        return
+    ns = len(segs)
+    ld_dy, ld_x = segs[0][0].stride(0), segs[0][1].stride(0)
+    assert all(dy.stride(0) == ld_dy and x.stride(0) == ld_x and dy.shape[0] == x.shape[0] for dy, x in segs)
+    npts = (C.c_int64 * ns)(*[dy.shape[0] for dy, _ in segs])
+    dys = (C.c_void_p * ns)(*[dy.data_ptr() for dy, _ in segs])
+    xs = (C.c_void_p * ns)(*[x.data_ptr() for _, x in segs])
     dwp = C.c_void_p(dw.data_ptr() + 4 * dw_col0)
-    check(lib.rsn_weight_grad(dy.shape[0], ptr(dy), dy.stride(0), n_out, ptr(x), x.stride(0), k_in, ptr(col_map), dwp,
-                              dw.stride(0), ptr(db), ops._stream()))
+    check(lib.rsn_weight_grad_multi(ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp, dw.stride(0),
+                                    ptr(db), ops._stream()))
 
 
-def _weight_grads(field, saved: Dict[str, Tensor], gout: Dict[str, Tensor], acc: _GradAcc, with_heads: bool):
-    """dW = dY^T X (+ db) for every linear layer of one field evaluation: rsn_weight_grad, accumulated in place."""
+def _weight_grads(field, levels, acc: _GradAcc):
+    """dW = dY^T X (+ db) for every linear layer, reduced over all field evaluations of the step at once.
+    levels: list of (saved activations, backward-sweep outputs, with_heads)."""
     L, W = field.mlp_base.num_layers, field.width
     skip = field.field_desc().skip_layer
     enc_map, sh_map = field._enc_col_map, field._sh_col_map
     g = acc.g
     for l in range(L):
-        dy = gout["dy"][l]
         gw, gb = g[f"mlp_base.layers.{l}.weight"], g[f"mlp_base.layers.{l}.bias"]
         if l == 0:
-            _wgrad(dy, W, saved["enc"], ENC_SLOTS, gw, 0, gb, enc_map)
+            _wgrad_multi([(go["dy"][l], sv["enc"]) for sv, go, _ in levels], W, ENC_SLOTS, gw, 0, gb, enc_map)
         elif l == skip:
-            _wgrad(dy, W, saved["enc"], ENC_SLOTS, gw, 0, gb, enc_map)
-            _wgrad(dy, W, saved["act"][l - 1], W, gw, 99, None)
+            _wgrad_multi([(go["dy"][l], sv["enc"]) for sv, go, _ in levels], W, ENC_SLOTS, gw, 0, gb, enc_map)
+            _wgrad_multi([(go["dy"][l], sv["act"][l - 1]) for sv, go, _ in levels], W, W, gw, 99, None)
         else:
-            _wgrad(dy, W, saved["act"][l - 1], W, gw, 0, gb)
-    emb = saved["act"][L - 1]
-    _wgrad(gout["d_bott"], W, emb, W, g["field_output_bottleneck.net.weight"], 0, g["field_output_bottleneck.net.bias"])
-    _wgrad(gout["da_mid"], 128, saved["sh"], SH_SLOTS, g["mlp_mid.layers.0.weight"], 0, g["mlp_mid.layers.0.bias"], sh_map)
-    _wgrad(gout["da_mid"], 128, saved["bott"], W, g["mlp_mid.layers.0.weight"], 34, None)
-    _wgrad(gout["dz_rgb"], 3, saved["hid"], 128, g["field_output_mid.net.weight"], 0, g["field_output_mid.net.bias"])
-    if with_heads:
-        _wgrad(gout["dz_heads"], 16, emb, W, acc.heads_w, 0, acc.heads_b)
+            _wgrad_multi([(go["dy"][l], sv["act"][l - 1]) for sv, go, _ in levels], W, W, gw, 0, gb)
+    emb = [(sv["act"][L - 1], go) for sv, go, _ in levels]
+    _wgrad_multi([(go["d_bott"], e) for e, go in emb], W, W, g["field_output_bottleneck.net.weight"], 0,
+                 g["field_output_bottleneck.net.bias"])
+    _wgrad_multi([(go["da_mid"], sv["sh"]) for sv, go, _ in levels], 128, SH_SLOTS, g["mlp_mid.layers.0.weight"], 0,
+                 g["mlp_mid.layers.0.bias"], sh_map)
+    _wgrad_multi([(go["da_mid"], sv["bott"]) for sv, go, _ in levels], 128, W, g["mlp_mid.layers.0.weight"], 34, None)
+    _wgrad_multi([(go["dz_rgb"], sv["hid"]) for sv, go, _ in levels], 3, 128, g["field_output_mid.net.weight"], 0,
+                 g["field_output_mid.net.bias"])
+    _wgrad_multi([(go["dz_heads"], sv["act"][L - 1]) for sv, go, wh in levels if wh], 16, W, acc.heads_w, 0, acc.heads_b)
 
 
 def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], need_input: bool):
@@ -283,6 +301,7 @@ class GetOutputsTrain(torch.autograd.Function):
         g_rgb_c, g_rgb_f = z(g_rgb_c, R, 3), z(g_rgb_f, R, 3)
         g_refl_c, g_refl_f = z(g_refl_c, R, 3), z(g_refl_f, R, 3)
         acc = _GradAcc(fld)
+        pending = []  # (saved, gout, with_heads) of every field evaluation: weight gradients in one pass at the end
         cf, rs = st["cf"], st["rs"]
         g_rough_ray = z(g_rough, R, 1).reshape(R).clone()
 
@@ -300,20 +319,18 @@ class GetOutputsTrain(torch.autograd.Function):
                 g_bg += cb["g_bg"]
                 gout = _field_backward(fld, st["rays2"], eb, lv, {"color": cb["g_color"]}, need_input=True)
                 g_pa2 += _ray_sum(gout["d_input"], M, S)
-                _weight_grads(fld, lv["saved"], gout, acc, with_heads=True)
-                del gout
+                pending.append((lv["saved"], gout, True))
             # get_inf_color
             gout, gst = _alloc_gout(fld, M, dev, True)
             desc = fld.field_desc()
             fs = _saved_struct(st["inf_saved"])
             check(lib.rsn_field_backward_inf(C.byref(desc), ptr(fld.packed_weights()), M, None, ptr(st["rays2"][1]),
                                              ptr(st["sq"]), C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream()))
-            _weight_grads(fld, st["inf_saved"], gout, acc, with_heads=False)
+            pending.append((st["inf_saved"], gout, False))
             g_r = torch.empty(R, device=dev)
             check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
                                            ptr(gout["d_input"]), ptr(g_pa2), ptr(g_r), ops._stream()))
             g_rough_ray += g_r
-            del gout
 
         # fine primary level (+ the live accumulation of the non-reflected rays' default reflect colour)
         lf = st["lf"]
@@ -326,8 +343,7 @@ class GetOutputsTrain(torch.autograd.Function):
                "pred_normals": ops._f32c(g_pn_f) if g_pn_f is not None else None,
                "n_dot_d": ops._f32c(g_ndd_f.reshape(R, Sf)) if g_ndd_f is not None else None}
         gout = _field_backward(fld, st["rays"], st["eb_f"], lf, gin, need_input=False)
-        _weight_grads(fld, lf["saved"], gout, acc, with_heads=True)
-        del gout
+        pending.append((lf["saved"], gout, True))
         # coarse primary level
         lc, cc = st["lc"], st["cc"]
         cb = _composite_backward(R, Sc, 1, CLIP, 0, lc, st["eb_c"], cc["weights"], g_rgb_c)
@@ -335,8 +351,9 @@ class GetOutputsTrain(torch.autograd.Function):
                "pred_normals": ops._f32c(g_pn_c) if g_pn_c is not None else None,
                "n_dot_d": ops._f32c(g_ndd_c.reshape(R, Sc)) if g_ndd_c is not None else None}
         gout = _field_backward(fld, st["rays"], st["eb_c"], lc, gin, need_input=False)
-        _weight_grads(fld, lc["saved"], gout, acc, with_heads=True)
-        del gout
+        pending.append((lc["saved"], gout, True))
+        _weight_grads(fld, pending, acc)
+        del pending, gout
 
         final = acc.finish()
         grads = [final.get(name) for name, _ in fld.named_parameters()]  # field_output_low: unused -> None

@@ -688,3 +688,37 @@ def test_fused_radam_matches_torch_optim(dev):
         assert max_abs(pg.detach().cpu(), pr.detach()) <= 2e-6
     assert pkg.exponential_decay_lr(0) == 1e-3 and abs(pkg.exponential_decay_lr(50000) - 1e-4) < 1e-12
     assert abs(pkg.exponential_decay_lr(25000) - (1e-3 * 1e-4) ** 0.5) < 1e-12
+
+
+@pytest.mark.parametrize("n_out,k_in,ld_dy,ld_x", [
+    (256, 256, 256, 256),  # trunk layer: vector loads of X and dY
+    (256, 104, 256, 104),  # encoded inputs (column map in the training graph)
+    (128, 40, 128, 40),    # mlp_mid, SH part: dwordx2 X loads
+    (16, 256, 16, 256),    # heads block: one row block, waves split the points
+    (3, 128, 4, 128),      # RGB head
+    (250, 99, 251, 99),    # odd sizes: scalar-load fallback for both operands
+    (37, 130, 38, 132),    # X vector path impossible (130 % 8): scalar loads, odd row count
+])
+def test_weight_grad_segments_and_shapes(dev, n_out, k_in, ld_dy, ld_x):
+    """rsn_weight_grad_multi: dW = sum over all segments of dY^T X, db = column sums; against fp64 matmul.
+    Segment lengths cover empty segments, lengths below one pipeline stage and non-multiples of the stage."""
+    from reflect_sampling_nerf_amd.train_graph import _wgrad_multi
+
+    g = torch.Generator().manual_seed(n_out * 1000 + k_in)
+    lens = [1000, 0, 37, 5003, 3]
+    segs, ref_w, ref_b = [], torch.zeros(n_out, k_in, dtype=torch.float64), torch.zeros(n_out, dtype=torch.float64)
+    for n in lens:
+        dy = torch.randn(n, ld_dy, generator=g)
+        x = torch.randn(n, ld_x, generator=g)
+        ref_w += dy[:, :n_out].double().t() @ x[:, :k_in].double()
+        ref_b += dy[:, :n_out].double().sum(0)
+        segs.append((dy.to(dev), x.to(dev)))
+    dw = torch.zeros(n_out, k_in + 5, device=dev)  # leading dimension > k_in, accumulate at a column offset
+    db = torch.zeros(n_out, device=dev)
+    _wgrad_multi(segs, n_out, k_in, dw, 5, db)
+    _wgrad_multi(segs[:1], n_out, k_in, dw, 5, None)  # accumulation, no bias
+    ref_w1 = segs[0][0][:, :n_out].double().cpu().t() @ segs[0][1][:, :k_in].double().cpu()
+    scale = float(ref_w.abs().max())
+    assert float((dw[:, 5:].double().cpu() - ref_w - ref_w1).abs().max()) <= 2e-5 * scale
+    assert float(dw[:, :5].abs().max()) == 0.0
+    assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
