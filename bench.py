@@ -133,9 +133,7 @@ def train_leg(pkg, args, dev, rank, world, dist, share):
         t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    with torch.no_grad():
-        model.eval()
-        mask_frac = float(model(rb)["mask"].float().mean())
+    mask_frac = float(model._train_aux["mask"].float().mean())  # rays that took the reflect branch in the last step
     return {"value": world * R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
             "warmup": warmup, "n_gpus": world, "dtype": "f32", "loss": float(loss), "reflect_ray_fraction": mask_frac,
             "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect (64 + 64) per rank, forward + "

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 8
+#define RSN_ABI_VERSION 9
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -116,7 +116,8 @@ const char* rsn_last_error(void);
 
 /* ---- weights: nn.Linear layout -> MFMA fragment order ---------------------------------------
  * The field kernels stream weights in the exact order the 32x32x2 f32 MFMA consumes them; this
- * re-lays the Field's parameters into one flat buffer (done once per optimiser step). */
+ * re-lays the Field's parameters into one flat buffer (done once per optimiser step).  The split-bf16
+ * copies of the segments are written only when desc->mma_mode != RSN_MMA_F32: re-pack after changing it. */
 size_t rsn_packed_weights_bytes(const rsn_field_desc* desc);
 int rsn_pack_weights(const rsn_field_desc* desc, const rsn_field_params* params, float* packed,
                      size_t packed_bytes, void* stream);
@@ -293,6 +294,16 @@ typedef struct rsn_composite_bwd_io {
 
 int rsn_composite_backward(int32_t n_rays, const int32_t* n_dev, int32_t n_samples, int32_t background, int32_t flags,
                            int32_t detach_weights, const rsn_composite_bwd_io* io, void* stream);
+
+/* Standalone encoders: what calling the Field's encoding modules directly computes.
+ * rsn_sh34_encode: IntegratedSHEncoding.forward (components.py:52-140): 34 real-SH terms of bands l = 1, 2, 4, 8 of
+ *   `directions` [n,3], band l attenuated by exp(-l(l+1)/2 * roughness) (roughness [n] or NULL = 0); out [n,34].
+ * rsn_ipe_encode: nerfstudio NeRFEncoding(3, 16, 0, 16, include_input=True).forward(means, covs) as the Field calls
+ *   it (field.py:129-131): out [n,99] = [sin block 48 | sin(.+pi/2) block 48 | raw 3], each block coord-major /
+ *   freq-minor, scaled by exp(-0.5 var f^2) when cov_diag [n,3] is given.  freqs16: HOST array of the 16 frequencies. */
+int rsn_sh34_encode(int64_t n, const float* directions, const float* roughness, float* out, void* stream);
+int rsn_ipe_encode(int64_t n, const float* means, const float* cov_diag, const float* freqs16, float* out,
+                   void* stream);
 
 /* rsn_weight_grad: dW[n][col_map ? col_map[k] : k] += sum_m dY[m][n] * X[m][k]  and  db[n] += sum_m dY[m][n]
  * (n < n_out <= 256, k < k_in <= 256; entries with col_map[k] < 0 are dropped).  The weight-gradient GEMM of

@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 8
+RSN_ABI_VERSION = 9
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -108,6 +108,8 @@ _SIGNATURES = {
                                          C.POINTER(CompositeBwdIO), C.c_void_p]),
     "rsn_weight_grad": (C.c_int, [C.c_int64, _fp, C.c_int32, C.c_int32, _fp, C.c_int32, C.c_int32, _fp, _fp, C.c_int32,
                                   _fp, C.c_void_p]),
+    "rsn_sh34_encode": (C.c_int, [C.c_int64, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_ipe_encode": (C.c_int, [C.c_int64, _fp, _fp, C.POINTER(C.c_float), _fp, C.c_void_p]),
     "rsn_weight_grad_multi": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                         C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _fp, C.c_void_p, C.c_int32, _fp,
                                         C.c_void_p]),

@@ -106,62 +106,6 @@ __device__ __forceinline__ void frustum_to_contracted(const float o[3], const fl
   }
 }
 
-// 34 real-SH polynomial terms, bands l = 1, 2, 4, 8 (reflect_sampling_nerf_components.py:65-127), then the
-// per-band roughness attenuation exp(-rho*{1,3,10,36}) (components.py:136-139).
-__device__ __forceinline__ void sh34_attenuated(float x, float y, float z, float rho, float sh[34]) {
-  const float x2 = x * x, y2 = y * y, z2 = z * z;
-  const float xy = x * y, xz = x * z, yz = y * z;
-  const float a = x2 - y2;
-  const float p = 3.0f * x2 - y2;
-  const float q = x2 - 3.0f * y2;
-  const float z4 = z2 * z2, x4 = x2 * x2, y4 = y2 * y2;
-  const float im5 = y4 - 10.0f * x2 * y2 + 5.0f * x4;
-  const float re5 = x4 - 10.0f * x2 * y2 + 5.0f * y4;
-  const float im7 = (x2 - 5.0f * y2) * 7.0f * x4 + (21.0f * x2 - y2) * y4;
-  const float re7 = (x2 - 21.0f * y2) * x4 + (5.0f * x2 - y2) * 7.0f * y4;
-  const float re4 = x2 * q - y2 * p;
-  const float t6 = 143.0f * z4 * z2 - 143.0f * z4 + 33.0f * z2 - 1.0f;
-  const float t7 = 715.0f * z4 * z2 - 1001.0f * z4 + 385.0f * z2 - 35.0f;
-  const float t5 = 39.0f * z4 - 26.0f * z2 + 3.0f;
-  const float t4 = 65.0f * z4 - 26.0f * z2 + 1.0f;
-  const float e1 = expf(-rho), e2 = expf(-rho * 3.0f), e4 = expf(-rho * 10.0f), e8 = expf(-rho * 36.0f);
-  sh[0] = 0.48860251190291992f * y * e1;
-  sh[1] = 0.48860251190291992f * z * e1;
-  sh[2] = 0.48860251190291992f * x * e1;
-  sh[3] = 1.09254843059207907f * xy * e2;
-  sh[4] = 1.09254843059207907f * yz * e2;
-  sh[5] = 0.31539156525252001f * (3.0f * z2 - 1.0f) * e2;
-  sh[6] = 1.09254843059207907f * xz * e2;
-  sh[7] = 0.54627421529603953f * a * e2;
-  sh[8] = 2.50334294179670453f * xy * a * e4;
-  sh[9] = 1.77013076977993053f * yz * p * e4;
-  sh[10] = 0.94617469575756001f * xy * (7.0f * z2 - 1.0f) * e4;
-  sh[11] = 0.66904654355728916f * yz * (7.0f * z2 - 3.0f) * e4;
-  sh[12] = 0.1057855469152043038f * (35.0f * z4 - 30.0f * z2 + 3.0f) * e4;
-  sh[13] = 0.66904654355728916f * xz * (7.0f * z2 - 3.0f) * e4;
-  sh[14] = 0.473087347878780009f * a * (7.0f * z2 - 1.0f) * e4;
-  sh[15] = 1.77013076977993053f * xz * q * e4;
-  sh[16] = 0.62583573544917613f * re4 * e4;
-  sh[17] = 5.83141328139863895f * xy * (x2 * x4 - 7.0f * x4 * y2 + 7.0f * x2 * y4 - y2 * y4) * e8;
-  sh[18] = 5.83141328139863895f * yz * im7 * e8;
-  sh[19] = 1.06466553211908514f * xy * (15.0f * z2 - 1.0f) * (3.0f * x4 - 10.0f * x2 * y2 + 3.0f * y4) * e8;
-  sh[20] = 3.44991062209810801f * yz * (5.0f * z2 - 1.0f) * im5 * e8;
-  sh[21] = 1.91366609903732278f * xy * t4 * a * e8;
-  sh[22] = 1.23526615529554407f * yz * t5 * p * e8;
-  sh[23] = 0.91230451686981894f * xy * t6 * e8;
-  sh[24] = 0.1090412458987799555f * yz * t7 * e8;
-  sh[25] = 0.0090867704915649962938f *
-           (6435.0f * z4 * z4 - 12012.0f * z4 * z2 + 6930.0f * z4 - 1260.0f * z2 + 35.0f) * e8;
-  sh[26] = 0.1090412458987799555f * xz * t7 * e8;
-  sh[27] = 0.456152258434909470f * t6 * a * e8;
-  sh[28] = 1.23526615529554407f * xz * t5 * q * e8;
-  sh[29] = 0.478416524759330697f * t4 * re4 * e8;
-  sh[30] = 3.44991062209810801f * xz * (5.0f * z2 - 1.0f) * re5 * e8;
-  sh[31] = 0.53233276605954257f * (15.0f * z2 - 1.0f) * (x2 * re5 - y2 * im5) * e8;
-  sh[32] = 5.83141328139863895f * xz * re7 * e8;
-  sh[33] = 0.72892666017482986f * (x2 * re7 - y2 * im7) * e8;
-}
-
 // Optional per-phase cycle accounting (debug builds only: tools/phase_report.py compiles a second library with
 // -DRSN_PHASE_TIMERS).  Wave 0 of every workgroup sums shader-clock deltas per phase; never part of librsn_hip.so.
 #ifdef RSN_PHASE_TIMERS

@@ -448,7 +448,8 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   rows_natural(j, W);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
 
-  // ---------------- split-bf16 copies (RSN_MMA_BF16X6 / X3) of every GEMM segment ----------------
+  // ---------------- split-bf16 copies (RSN_MMA_BF16X6 / X3 / BF16) of every GEMM segment ----------------
+  if (d->mma_mode == RSN_MMA_F32) return RSN_OK;  // the exact-fp32 kernels never read them
   if ((rc = split_seg(packed + L.w_enc0, RSN_ENC_ITS, NB, packed + L.h_enc0, st)) != RSN_OK) return rc;
   for (int l = 1; l < d->num_layers; ++l) {
     if ((rc = split_seg(packed + L.w_x[l], NB * 4, NB, packed + L.h_x[l], st)) != RSN_OK) return rc;

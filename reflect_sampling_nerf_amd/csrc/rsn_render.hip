@@ -5,7 +5,7 @@
 // Reference semantics restated: nerfstudio SpacedSampler/PDFSampler/get_weights/renderers (SURVEY
 // §8(a) N5, N7-N11), reflect_sampling_nerf_components.py:14-36 (reciprocal spacing),
 // reflect_sampling_nerf_model.py:215-229,240-241,267-289,312-313,338-339.
-#include "rsn_common.h"
+#include "rsn_mfma.h"  // shared device math (sin_big, sh34_attenuated); includes rsn_common.h
 
 // ---------------------------------------------------------------------------------------------------
 // helpers
@@ -750,6 +750,42 @@ __global__ void rsn_reflection_kernel(long long n, const float* d_, const float*
   }
 }
 
+// Standalone encoders (the Field's `direction_encoding(...)` / `position_encoding(...)` modules called directly);
+// inside the field kernels the same arithmetic is fused (rsn_field.hip).  Output columns in the reference's order.
+__global__ void rsn_sh34_kernel(long long n, const float* dirs, const float* rough, float* out) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float sh[34];
+  sh34_attenuated(dirs[p * 3], dirs[p * 3 + 1], dirs[p * 3 + 2], rough ? rough[p] : 0.0f, sh);
+#pragma unroll
+  for (int i = 0; i < 34; ++i) out[p * 34 + i] = sh[i];
+}
+
+struct IpeFreqs {
+  float f[RSN_NUM_FREQS];
+};
+
+// one thread per (point, coordinate): columns c*16+j (sin), 48+c*16+j (sin(. + pi/2)), 96+c (raw input)
+__global__ void rsn_ipe_kernel(long long n3, const float* means, const float* cov_diag, IpeFreqs fr, float* out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n3) return;
+  const long long p = t / 3;
+  const int c = (int)(t - p * 3);
+  const float x = means[t];
+  const float v = cov_diag ? cov_diag[t] : 0.0f;
+  const float sx = 6.283185307179586f * x;
+  float* row = out + p * RSN_ENC_DIM;
+#pragma unroll 4
+  for (int j = 0; j < RSN_NUM_FREQS; ++j) {
+    const float f = fr.f[j];
+    const float ang = sx * f;
+    const float e = cov_diag ? expf(-0.5f * (v * (f * f))) : 1.0f;
+    row[c * 16 + j] = e * sin_big(ang);
+    row[48 + c * 16 + j] = e * sin_big(ang + 1.5707963267948966f);
+  }
+  row[96 + c] = x;
+}
+
 #define RSN_ELEMENTWISE_LAUNCH(kernel, n, ...)                                                          \
   do {                                                                                                  \
     const int threads = 256;                                                                            \
@@ -783,5 +819,24 @@ extern "C" int rsn_reflection(int64_t n, const float* directions, const float* n
   if (n == 0) return RSN_OK;
   RSN_REQUIRE(directions && normals, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
   RSN_ELEMENTWISE_LAUNCH(rsn_reflection_kernel, n, directions, normals, reflections, n_dot_d);
+  return RSN_OK;
+}
+
+extern "C" int rsn_sh34_encode(int64_t n, const float* directions, const float* roughness, float* out, void* stream) {
+  RSN_REQUIRE(n >= 0, RSN_ERR_INVALID_ARGUMENT, "n=%lld", (long long)n);
+  if (n == 0) return RSN_OK;
+  RSN_REQUIRE(directions && out, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  RSN_ELEMENTWISE_LAUNCH(rsn_sh34_kernel, n, directions, roughness, out);
+  return RSN_OK;
+}
+
+extern "C" int rsn_ipe_encode(int64_t n, const float* means, const float* cov_diag, const float* freqs16, float* out,
+                              void* stream) {
+  RSN_REQUIRE(n >= 0, RSN_ERR_INVALID_ARGUMENT, "n=%lld", (long long)n);
+  if (n == 0) return RSN_OK;
+  RSN_REQUIRE(means && freqs16 && out, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  IpeFreqs fr;
+  for (int i = 0; i < RSN_NUM_FREQS; ++i) fr.f[i] = freqs16[i];  // host array, like rsn_field_desc.freqs
+  RSN_ELEMENTWISE_LAUNCH(rsn_ipe_kernel, n * 3, means, cov_diag, fr, out);
   return RSN_OK;
 }

@@ -2,6 +2,7 @@
 memory and the stream; every arithmetic step runs in librsn_hip.so.  No fallbacks."""
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, Optional
 
 import torch
@@ -115,3 +116,31 @@ def field_outputs_struct(level: Dict[str, Tensor]) -> FieldOutputs:
     for name in ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density"):
         setattr(fo, name, ptr(level.get(name)))
     return fo
+
+
+def sh34_encode(directions: Tensor, roughness: Optional[Tensor] = None) -> Tensor:
+    """IntegratedSHEncoding.forward: [..., 3], [..., 1] or None -> [..., 34] (rsn_sh34_encode)."""
+    lib = _abi.load_library()
+    lead = directions.shape[:-1]
+    d = _f32c(directions.reshape(-1, 3))
+    n = d.shape[0]
+    r = _f32c(roughness.expand(*lead, 1).reshape(-1)) if roughness is not None else None
+    out = torch.empty(n, 34, device=d.device, dtype=torch.float32)
+    check(lib.rsn_sh34_encode(n, ptr(d), ptr(r), ptr(out), _stream()))
+    return out.reshape(*lead, 34)
+
+
+def ipe_encode(means: Tensor, covs: Optional[Tensor], freqs: Tensor) -> Tensor:
+    """NeRFEncoding.forward(means, covs): [..., 3] (+ [..., 3, 3] or diagonal [..., 3]) -> [..., 99] (rsn_ipe_encode)."""
+    lib = _abi.load_library()
+    lead = means.shape[:-1]
+    m = _f32c(means.reshape(-1, 3))
+    n = m.shape[0]
+    cd = None
+    if covs is not None:
+        cd = covs if covs.shape[-1] == 3 and covs.dim() == means.dim() else torch.diagonal(covs, dim1=-2, dim2=-1)
+        cd = _f32c(cd.reshape(-1, 3))
+    fr = (C.c_float * 16)(*[float(f) for f in freqs.tolist()])
+    out = torch.empty(n, 99, device=m.device, dtype=torch.float32)
+    check(lib.rsn_ipe_encode(n, ptr(m), ptr(cd), fr, ptr(out), _stream()))
+    return out.reshape(*lead, 99)

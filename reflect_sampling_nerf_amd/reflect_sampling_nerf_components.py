@@ -36,6 +36,13 @@ class NeRFEncoding(nn.Module):
         # same expression as nerfstudio's NeRFEncoding so the table is bit-identical to the reference's
         return 2 ** torch.linspace(self.min_freq, self.max_freq, self.num_frequencies)
 
+    def forward(self, in_tensor: Tensor, covs: Optional[Tensor] = None) -> Tensor:
+        """[..., 3] (+ covs [..., 3, 3], only the diagonal is used) -> [..., 99] via rsn_ipe_encode: what the Field's
+        `self.position_encoding(mean, covs=cov)` returns in the reference (field.py:129-131).  Eval only."""
+        if (self.in_dim, self.num_frequencies, self.include_input) != (3, 16, True):
+            raise NotImplementedError("only NeRFEncoding(3, 16, ..., include_input=True) is implemented")
+        return ops.ipe_encode(in_tensor, covs, self.frequencies())
+
 
 class IntegratedSHEncoding(nn.Module):
     """Roughness-attenuated real SH, bands l in {1,2,4,8}: 34 channels (components.py:38-140).
@@ -47,6 +54,11 @@ class IntegratedSHEncoding(nn.Module):
 
     def get_out_dim(self) -> int:
         return 34
+
+    def forward(self, directions: Tensor, roughness: Optional[Tensor] = None) -> Tensor:
+        """directions [..., 3], roughness [..., 1] (or None) -> [..., 34] via rsn_sh34_encode (components.py:52-140;
+        no gradient flows through the encoding in the reference either: computed under no_grad)."""
+        return ops.sh34_encode(directions, roughness)
 
 
 @dataclass

@@ -118,6 +118,7 @@ class ReflectSamplingNeRFNerfField(Field):
         (plain bf16 operands, fp32 accumulate: BASELINE configs[3])."""
         self.mma_mode = self.MMA_MODES[mode]
         self._desc = None
+        self._packed_key = None  # rsn_pack_weights writes the split-bf16 segments only for the modes that read them
 
     # ------------------------------------------------------------------ C-ABI plumbing
     @property

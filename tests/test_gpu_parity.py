@@ -722,3 +722,37 @@ def test_weight_grad_segments_and_shapes(dev, n_out, k_in, ld_dy, ld_x):
     assert float((dw[:, 5:].double().cpu() - ref_w - ref_w1).abs().max()) <= 2e-5 * scale
     assert float(dw[:, :5].abs().max()) == 0.0
     assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+
+
+def test_standalone_sh34_encoding_matches_reference_golden(dev):
+    """IntegratedSHEncoding called as a module (rsn_sh34_encode) against the output of the reference's own
+    IntegratedSHEncoding.forward (tests/golden/units.npz, oracle/make_golden.py) and against the oracle."""
+    _, g = load_golden("units")
+    enc = pkg.ReflectSamplingNeRFNerfField().direction_encoding
+    dirs, rough = g["sh"]["dirs"], g["sh"]["roughness"]
+    out = enc(dirs.to(dev), rough.to(dev)).cpu()
+    assert out.shape == (257, 34)
+    assert max_abs(out, g["sh"]["out"]) <= 1e-5
+    assert max_abs(out, cpu_ref.integrated_sh(dirs, rough)) <= 1e-5
+    # leading batch dims, no roughness (zero attenuation exponent)
+    d2 = torch.nn.functional.normalize(torch.randn(3, 5, 3, generator=torch.Generator().manual_seed(1)), dim=-1)
+    o2 = enc(d2.to(dev)).cpu()
+    assert o2.shape == (3, 5, 34)
+    assert max_abs(o2, cpu_ref.integrated_sh(d2, torch.zeros(3, 5, 1))) <= 1e-5
+
+
+def test_standalone_ipe_encoding_matches_oracle(dev):
+    """NeRFEncoding called as a module (rsn_ipe_encode): reference column order [sin 48 | cos 48 | raw 3]."""
+    fs = cpu_ref.FieldSpec()
+    enc = pkg.ReflectSamplingNeRFNerfField().position_encoding
+    gen = torch.Generator().manual_seed(3)
+    mean = (torch.rand(4, 33, 3, generator=gen) - 0.5) * 4.0  # contracted means live in the radius-2 ball
+    A = torch.randn(4, 33, 3, 3, generator=gen) * 0.02
+    cov = A @ A.transpose(-1, -2)
+    out = enc(mean.to(dev), covs=cov.to(dev)).cpu()
+    ref = cpu_ref.ipe(fs, mean, torch.diagonal(cov, dim1=-2, dim2=-1))
+    assert out.shape == (4, 33, 99)
+    # sin of arguments up to 2*pi*2*2^16: fp32 argument rounding is shared, the device sin is <= 1.5 ulp
+    assert max_abs(out, ref) <= 2e-6
+    out_nc = enc(mean.to(dev)).cpu()
+    assert max_abs(out_nc, cpu_ref.ipe(fs, mean, None)) <= 2e-6

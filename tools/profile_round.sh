@@ -8,6 +8,7 @@
 set -u
 TAG=${1:-r01}
 OUT=/root/repo/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 /root/repo/bench.py --no-cpu-baseline"

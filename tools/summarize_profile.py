@@ -8,7 +8,7 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 out = {"tag": tag, "kernel": KERNEL}
 # 1. kernel stats
-f = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
+f = max(glob.glob(f"{src}/stats/*/*_kernel_stats.csv"), key=os.path.getmtime)  # newest run (gpurun merges into old dirs)
 stats = list(csv.DictReader(open(f)))
 out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                         "pct": float(r["Percentage"])} for r in stats]
@@ -21,7 +21,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     if not fs:
         continue
     agg, dur = collections.defaultdict(list), []
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         if KERNEL in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
