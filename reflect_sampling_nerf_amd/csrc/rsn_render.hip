@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void rsn_composite_kernel(int n_rays, const in
       }
       const float dd = in ? (tb - ta) * sg : 0.0f;
       const double incl = wave_scan_incl((double)dd, lane);
-      const float excl = (float)((incl - (double)dd) + carry_dd);
+      // exclusive prefix = the previous lane's inclusive one (not incl - dd: an infinite dd must not poison its own T)
+      const double prev = __shfl_up(incl, 1, 64);
+      const float excl = (float)((lane > 0 ? prev : 0.0) + carry_dd);
       carry_dd += __shfl(incl, 63, 64);
       const float alpha = 1.0f - expf(-dd);
       const float T = expf(-excl);

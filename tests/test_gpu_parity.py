@@ -756,3 +756,39 @@ def test_standalone_ipe_encoding_matches_oracle(dev):
     assert max_abs(out, ref) <= 2e-6
     out_nc = enc(mean.to(dev)).cpu()
     assert max_abs(out_nc, cpu_ref.ipe(fs, mean, None)) <= 2e-6
+
+
+def test_empty_ray_bundle(dev):
+    """R = 0: every output exists with a zero-length leading dimension; nothing is launched on an empty batch."""
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=8, num_importance_samples=8, num_reflect_coarse_samples=4,
+                                            num_reflect_importance_samples=4, base_mlp_num_layers=4,
+                                            base_mlp_layer_width=64)
+    model = cfg.setup(scene_box=None, num_train_data=1).to(dev).eval()
+    z = torch.zeros(0, 3, device=dev)
+    out = model(pkg.RayBundle(origins=z, directions=z, pixel_area=torch.zeros(0, 1, device=dev)))
+    assert tuple(out["mid_rgb_fine"].shape) == (0, 3) and tuple(out["mask"].shape) == (0,)
+    assert tuple(out["weights_fine"].shape) == (0, 8, 1) and tuple(out["pred_normals_coarse"].shape) == (0, 8, 3)
+    assert "depth_reflect_fine" not in out
+
+
+def test_composite_non_finite_and_saturated_density(dev):
+    """RaySamples.get_weights (N5) ends in nan_to_num: infinite / NaN / huge densities must give the oracle's weights
+    (no NaN leaves the compositor), also when a bin has zero width."""
+    R, S = 6, 9
+    g = torch.Generator().manual_seed(11)
+    eb = torch.sort(torch.rand(R, S + 1, generator=g) * 4.0 + 2.0, dim=-1).values
+    eb[1, 3] = eb[1, 4]  # zero-width bin
+    sigma = torch.rand(R, S, generator=g) * 3.0
+    sigma[0, 2] = float("inf")
+    sigma[2, 0] = 1e30
+    sigma[3, 5] = float("nan")
+    sigma[4, :] = 0.0
+    color = torch.rand(R, S, 3, generator=g)
+    out = ops.composite(R, None, S, 1, ops.RSN_COMP_EVAL | ops.RSN_COMP_CLIP_RGB, sigma.to(dev), eb.to(dev),
+                        color.to(dev))
+    w_ref = cpu_ref.weights_from_density(sigma[..., None], eb[:, :-1], eb[:, 1:])[..., 0]
+    w = out["weights"].cpu()
+    assert bool(torch.isfinite(w).all())
+    assert max_abs(w, w_ref) <= 1e-6
+    rgb_ref = cpu_ref.composite_rgb(color, w_ref[..., None], torch.ones(3), training=False)
+    assert max_abs(out["rgb"].cpu(), torch.clip(rgb_ref, 0.0, 1.0)) <= 1e-5
