@@ -792,3 +792,32 @@ def test_composite_non_finite_and_saturated_density(dev):
     assert max_abs(w, w_ref) <= 1e-6
     rgb_ref = cpu_ref.composite_rgb(color, w_ref[..., None], torch.ones(3), training=False)
     assert max_abs(out["rgb"].cpu(), torch.clip(rgb_ref, 0.0, 1.0)) <= 1e-5
+
+
+@pytest.mark.parametrize("kind,tan,near,far", [("uniform", 1.0, 2.0, 6.0), ("reciprocal", 0.25, 0.0, 256.0)])
+def test_pdf_sampler_degenerate_histograms(dev, kind, tan, near, far):
+    """Inverse-CDF resampling (N9) on histograms that exercise its guards: one-hot weights (flat CDF runs: 0/0 -> 0),
+    weights far below the 1e-5 padding threshold, a single dominant bin at either end, equal weights."""
+    R, S_in, S_out = 8, 12, 40
+    g = torch.Generator().manual_seed(17)
+    w = torch.zeros(R, S_in, 1)
+    w[0, 5] = 1.0
+    w[1] = 1e-12
+    w[2, 0] = 1.0
+    w[3, S_in - 1] = 1.0
+    w[4] = 1.0 / S_in
+    w[5] = torch.rand(S_in, 1, generator=g) * 1e-7
+    w[6, 3], w[6, 9] = 0.5, 0.5
+    w[7] = torch.rand(S_in, 1, generator=g)
+    nears, fars = torch.full((R, 1), near), torch.full((R, 1), far)
+    sb_in, _ = cpu_ref.spaced_bins(kind, tan, nears, fars, S_in, None)
+    code = RSN_SPACING_UNIFORM if kind == "uniform" else RSN_SPACING_RECIPROCAL
+    for u_rand in (None, torch.rand(R, S_out + 1, generator=g)):
+        sb_ref, eb_ref = cpu_ref.pdf_bins(kind, tan, nears, fars, w, sb_in, S_out, u_rand)
+        sb, eb = ops.sample_pdf(R, None, S_in, S_out, code, tan, 0.01, nears.reshape(R).to(dev), fars.reshape(R).to(dev),
+                                w[..., 0].contiguous().to(dev), sb_in.contiguous().to(dev),
+                                None if u_rand is None else u_rand.to(dev))
+        assert bool(torch.isfinite(sb).all()) and bool(torch.isfinite(eb).all())
+        assert max_abs(sb.cpu(), sb_ref) <= 1e-5
+        # euclidean bins of the reciprocal spacing reach 256: relative bound
+        assert float(((eb.cpu() - eb_ref).abs() / (1.0 + eb_ref.abs())).max()) <= 2e-5
