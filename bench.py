@@ -133,7 +133,8 @@ def train_leg(pkg, args, dev, rank, world, dist, share):
         t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    mask_frac = float(model._train_aux["mask"].float().mean())  # rays that took the reflect branch in the last step
+    with torch.no_grad():  # rays that take the reflect branch after the timed steps (training-mode forward, untimed)
+        mask_frac = float(model(rb)["mask"].float().mean())
     return {"value": world * R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
             "warmup": warmup, "n_gpus": world, "dtype": "f32", "loss": float(loss), "reflect_ray_fraction": mask_frac,
             "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect (64 + 64) per rank, forward + "
@@ -287,8 +288,13 @@ def main():
                       "bf16": "bf16 (bf16 MFMA operands, f32 accumulate; BASELINE configs[3])"}[args.mma],
             "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[1]: %d rays x %d samples, %d-layer %d-wide MLP, fp32, fused forward + "
-                             "composite of one sampling level (eval)" % (R, S, args.layers, args.width))
+                "workload": ("%s: %d rays x %d samples, %d-layer %d-wide MLP, %s, fused forward + composite of one "
+                             "sampling level (eval)" %
+                             ("BASELINE configs[1]" if (R, S, args.mma) == (4096, 128, "f32") else
+                              "BASELINE configs[3]" if (R, S, args.mma) == (16384, 192, "bf16") else "custom size",
+                              R, S, args.layers, args.width,
+                              {"f32": "fp32", "bf16x6": "fp32 emulated on bf16 MFMA (6 products)",
+                               "bf16x3": "bf16x3 split", "bf16": "bf16 MFMA hidden GEMMs"}[args.mma]))
                 if args.workload == "level" else
                 ("full %s: %d rays x (%d coarse + %d fine + reflect %d + %d), %dx%d field, M/R=%.2f" %
                  ("training step (forward+loss+backward+grad all-reduce+RAdam, BASELINE configs[2])"
@@ -309,11 +315,15 @@ def main():
             if flop is not None:
                 achieved = flop / (kms * 1e-3) / 1e12
                 traffic = None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-                try:
-                    summ = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_summary.json"))
-                    with open(os.path.join(REPO, "profiles", summ[-1])) as fh:
-                        traffic = json.load(fh).get("hbm_traffic_bytes_per_launch")
-                except (OSError, IndexError, ValueError):
+                kname = "rsn_field_kernel<8, false, %d>" % {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}[args.mma]
+                try:  # newest summary (by name) that was taken on this kernel instantiation and this workload size
+                    for fn in sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_summary.json")):
+                        with open(os.path.join(REPO, "profiles", fn)) as fh:
+                            js = json.load(fh)
+                        if js.get("kernel") == kname and js.get("rays", 4096) == R and js.get("samples", 128) == S \
+                                and js.get("hbm_traffic_bytes_per_launch") is not None:
+                            traffic = js["hbm_traffic_bytes_per_launch"]
+                except (OSError, ValueError):
                     pass
                 # f32: algorithmic FLOP against the fp32-MFMA peak.  Split modes issue 6 (3) bf16 MFMA FLOP per
                 # algorithmic FLOP: priced as issued bf16 FLOP against the bf16 dense peak.

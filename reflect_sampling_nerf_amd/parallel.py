@@ -29,6 +29,7 @@ class FlatGradAllReduce:
         n = self.total + len(self.params)  # gradients + one "was used" flag per parameter
         if self._flat is None or self._flat.device != device or self._flat.dtype != dtype:
             self._flat = torch.zeros(n, device=device, dtype=dtype)
+            self._views = [v.view_as(p) for v, p in zip(self._flat[: self.total].split(self.sizes), self.params)]
         return self._flat
 
     @torch.no_grad()
@@ -40,13 +41,14 @@ class FlatGradAllReduce:
             return
         p0 = self.params[0]
         flat = self._buffer(p0.device, p0.dtype)
-        flat.zero_()
-        off = 0
-        for i, (p, n) in enumerate(zip(self.params, self.sizes)):
-            if p.grad is not None:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-                flat[self.total + i] = 1.0
-            off += n
+        have = [p.grad is not None for p in self.params]
+        # pack: one multi-tensor copy for the gradients that exist, zeros elsewhere, the flags in one transfer
+        if not all(have):
+            flat[: self.total].zero_()
+        src = [p.grad for p, h in zip(self.params, have) if h]
+        if src:
+            torch._foreach_copy_([v for v, h in zip(self._views, have) if h], src)
+        flat[self.total:].copy_(torch.tensor([1.0 if h else 0.0 for h in have], dtype=flat.dtype), non_blocking=True)
         if dist.get_backend(self.group) == "gloo" and flat.is_cuda:  # CPU rehearsal backend: stage through host
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -54,15 +56,15 @@ class FlatGradAllReduce:
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat[: self.total].mul_(1.0 / world)
-        off = 0
-        for i, (p, n) in enumerate(zip(self.params, self.sizes)):
-            if float(flat[self.total + i]) > 0.0:  # used on at least one rank
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-            off += n
+        # unpack: gradients that exist locally are overwritten in one multi-tensor copy; only when this rank lacks
+        # some does it need the summed flags (one host read) to tell "zeros" from "unused everywhere -> stays None"
+        if src:
+            torch._foreach_copy_(src, [v for v, h in zip(self._views, have) if h])
+        if not all(have):
+            used = flat[self.total:].cpu()
+            for i, (p, h) in enumerate(zip(self.params, have)):
+                if not h and float(used[i]) > 0.0:
+                    p.grad = self._views[i].clone()
 
 
 def apply_loss_warmup(model, step: int) -> None:

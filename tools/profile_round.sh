@@ -4,14 +4,17 @@
 #   2. --pmc FETCH_SIZE                HBM read side   (separate pass: TCC has 4 slots, FETCH_SIZE takes 3)
 #   3. --pmc WRITE_SIZE                HBM write side
 #   4. --pmc SQ_* (two passes)         MFMA busy cycles, clock, waits, instruction mix
+# Usage: tools/profile_round.sh <tag> [extra bench.py arguments]
 # Output: gpurun_out/prof_<tag>/...; summarise with tools/summarize_profile.py into profiles/.
 set -u
 TAG=${1:-r01}
+shift || true
+EXTRA="$*"   # extra bench.py arguments, e.g. --rays 16384 --samples 192 --mma bf16 (BASELINE configs[3])
 OUT=/root/repo/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 /root/repo/bench.py --no-cpu-baseline"
+B="python3 /root/repo/bench.py --no-cpu-baseline $EXTRA"
 P="$B --no-train-leg"  # counter passes: headline kernels only
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B --steps 20 --warmup 5 > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $P --steps 5 --warmup 2 > $OUT/pmc_fetch.log 2>&1 || exit 1

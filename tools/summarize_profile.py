@@ -7,6 +7,12 @@ KERNEL = sys.argv[2] if len(sys.argv) > 2 else "rsn_field_kernel<8, false, 0>"  
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 out = {"tag": tag, "kernel": KERNEL}
+try:  # workload size of the profiled bench run
+    bl = json.loads(open(f"gpurun_out/prof_{tag}/bench_line.json").readline())
+    out["rays"], out["samples"] = bl["config"]["rays_per_gpu"], bl["config"]["samples_per_ray"]
+    out["bench_line"] = {k: bl[k] for k in ("value", "unit", "ms_per_step", "dtype") if k in bl}
+except (OSError, ValueError, KeyError):
+    pass
 # 1. kernel stats
 f = max(glob.glob(f"{src}/stats/*/*_kernel_stats.csv"), key=os.path.getmtime)  # newest run (gpurun merges into old dirs)
 stats = list(csv.DictReader(open(f)))
