@@ -560,6 +560,41 @@ def render_level(P, fs: FieldSpec, origins, directions, pixel_area, nears, fars,
             "weights": w, "level": lv}
 
 
+
+# --------------------------------------------------------------------------------------
+# get_loss_dict                                                          (model.py:346-430)
+# --------------------------------------------------------------------------------------
+LOSS_COEFFICIENTS = {  # model.py:56-69 (the four normal / orientation values are what the pipeline restores after the
+    # 50-step warm-up, pipeline.py:79-91); the four "low" terms are configured but never computed (model.py:348-430)
+    "loss_low_coarse": 0.1, "loss_low_fine": 0.1, "loss_mid_coarse": 1.0, "loss_mid_fine": 1.0,
+    "loss_reflect_low_coarse": 0.1, "loss_reflect_low_fine": 0.1, "loss_reflect_mid_coarse": 1.0,
+    "loss_reflect_mid_fine": 1.0, "predicted_normal_loss_coarse": 3e-5, "predicted_normal_loss_fine": 3e-4,
+    "orientation_loss_coarse": 1e-2, "orientation_loss_fine": 1e-1,
+}
+
+
+def loss_dict(out: Dict[str, Tensor], image: Tensor, coefficients: Optional[Dict[str, float]] = None) -> Dict[str, Tensor]:
+    """The eight scaled loss terms.  RGBRenderer.blend_background_for_loss_computation with the white background
+    (N10) leaves the prediction alone and blends the ground truth only when it carries alpha; MSELoss is the mean over
+    all elements; the normal / orientation terms are SUMS weighted by the (detached) weights (model.py:403-407)."""
+    coefficients = LOSS_COEFFICIENTS if coefficients is None else coefficients
+    if image.shape[-1] == 4:
+        image = image[..., :3] * image[..., 3:] + (1.0 - image[..., 3:])
+    mse = lambda a, b: torch.mean((a - b) ** 2)  # noqa: E731
+    terms = {
+        "loss_mid_coarse": mse(image, out["mid_rgb_coarse"]),
+        "loss_mid_fine": mse(image, out["mid_rgb_fine"]),
+        "loss_reflect_mid_coarse": mse(image, out["mid_reflect_coarse"]),
+        "loss_reflect_mid_fine": mse(image, out["mid_reflect_fine"]),
+    }
+    for lvl in ("coarse", "fine"):
+        w = out[f"weights_{lvl}"]
+        terms[f"predicted_normal_loss_{lvl}"] = torch.sum(
+            w * torch.sum((out[f"normals_{lvl}"] - out[f"pred_normals_{lvl}"]) ** 2, dim=-1, keepdim=True))
+        ndd = out[f"n_dot_d_{lvl}"]
+        terms[f"orientation_loss_{lvl}"] = torch.sum(w * torch.max(torch.zeros_like(ndd), ndd) ** 2)
+    return {k: v * coefficients[k] for k, v in terms.items() if k in coefficients}
+
 def synthetic_rays(R: int, seed: int = 0):
     """SURVEY §8(d) synthetic inputs: camera shell of radius 4 looking at the origin."""
     g = torch.Generator().manual_seed(seed)

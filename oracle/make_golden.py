@@ -130,6 +130,54 @@ def run_case(name, R, samples, layers, width, training, seed, density_bias_shift
     print(f"{name}: R={R} M={meta['M']} keys={len(out)} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_train_step_case(name, R, samples, layers, width, seed, density_bias_shift, near=2.0, far=6.0):
+    """One whole training step of the reference: get_outputs (train mode, logged jitter) -> get_loss_dict
+    (model.py:346-430, post-warm-up coefficients of the config) -> backward.  Stores the outputs, the eight scaled loss
+    terms and the gradient of their sum w.r.t. every Field parameter."""
+    model = build_model(samples, layers, width, seed, density_bias_shift)
+    o, d, pa = synthetic_rays(R, seed=seed + 100)
+    nears, fars = torch.full((R, 1), near), torch.full((R, 1), far)
+    bundle = RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=pa.clone(), nears=nears.clone(),
+                       fars=fars.clone())
+    image = torch.rand(R, 3, generator=torch.Generator().manual_seed(seed + 200))
+    model.train(True)
+    torch.manual_seed(seed + 7)
+    sink = io.StringIO()
+    with RandLog() as log, contextlib.redirect_stdout(sink):
+        out = model.get_outputs(bundle)
+        loss_dict = model.get_loss_dict(out, {"image": image})
+        total = sum(loss_dict.values())
+        total.backward()
+    arrays = {}
+    for k, v in model.field.state_dict().items():
+        arrays["param/" + k] = v.detach().numpy().astype(np.float32)
+    n_grad = 0
+    for k, p in model.field.named_parameters():
+        if p.grad is not None:
+            arrays["grad/" + k] = p.grad.detach().numpy().astype(np.float32)
+            n_grad += 1
+    for k, v in [("origins", o), ("directions", d), ("pixel_area", pa), ("nears", nears), ("fars", fars), ("image", image)]:
+        arrays["in/" + k] = v.numpy()
+    for k, v in out.items():
+        a = v.detach().numpy()
+        arrays["out/" + k] = a.astype(np.uint8) if a.dtype == np.bool_ else a.astype(np.float32)
+    for k, v in loss_dict.items():
+        arrays["loss/" + k] = np.float32(v.detach().item()).reshape(1)
+    assert len(log.draws) in (2, 4), len(log.draws)
+    for n, t in zip(["coarse", "fine", "reflect_coarse", "reflect_fine"], log.draws):
+        arrays["jitter/" + n] = t.numpy()
+    meta = dict(name=name, R=R, samples=list(samples), layers=layers, width=width, training=True, seed=seed,
+                density_bias_shift=density_bias_shift, near=near, far=far, M=int(out["mask"].sum()),
+                keys=sorted(out.keys()), loss_coefficients={k: float(v) for k, v in model.config.loss_coefficients.items()},
+                generator="oracle/make_golden.py over /root/reference + oracle/ns_shim (get_outputs + get_loss_dict + backward)",
+                torch=torch.__version__)
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: R={R} M={meta['M']} losses={len(loss_dict)} grads={n_grad} total={float(total):.6f} "
+          f"-> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def run_units(seed=3):
     """Direct goldens for reference-owned units: contract, IntegratedSHEncoding, ReciprocalSampler,
     get_inf_color, get_pred_normals, get_reflection."""
@@ -210,6 +258,9 @@ def main():
     # eval near plane 0 (collider reset in eval), wide far
     run_case("eval_l8_w64_near0", R=24, samples=(32, 32, 16, 16), layers=8, width=64, training=False, seed=5,
              density_bias_shift=1.5, near=0.0, far=6.0)
+    # one whole training step (forward + the reference's own get_loss_dict + backward) at a width the HIP path runs
+    run_train_step_case("trainstep_l8_w64", R=32, samples=(16, 16, 8, 8), layers=8, width=64, seed=6,
+                        density_bias_shift=2.0)
     run_units()
 
 

@@ -821,3 +821,61 @@ def test_pdf_sampler_degenerate_histograms(dev, kind, tan, near, far):
         assert max_abs(sb.cpu(), sb_ref) <= 1e-5
         # euclidean bins of the reciprocal spacing reach 256: relative bound
         assert float(((eb.cpu() - eb_ref).abs() / (1.0 + eb_ref.abs())).max()) <= 2e-5
+
+
+def test_train_step_against_reference_fixture(dev):
+    """One whole training step of the REFERENCE itself (tests/golden/trainstep_l8_w64.npz: get_outputs in train mode,
+    its own get_loss_dict, backward; generated by oracle/make_golden.py) against the HIP path with the reference's
+    parameters, rays, logged jitter and target image: outputs, the eight loss terms, every parameter gradient."""
+    meta, g = load_golden("trainstep_l8_w64")
+    s = meta["samples"]
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=s[0], num_importance_samples=s[1],
+                                            num_reflect_coarse_samples=s[2], num_reflect_importance_samples=s[3],
+                                            base_mlp_num_layers=meta["layers"], base_mlp_layer_width=meta["width"])
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    model.field.load_state_dict(g["param"])
+    model.to(dev).train()
+    assert dict(model.config.loss_coefficients) == pytest.approx(meta["loss_coefficients"])
+    i = g["in"]
+    rb = pkg.RayBundle(origins=i["origins"].to(dev), directions=i["directions"].to(dev),
+                       pixel_area=i["pixel_area"].to(dev), nears=i["nears"].to(dev), fars=i["fars"].to(dev))
+    out = model._get_outputs_train(rb, jitter={k: v.to(dev) for k, v in g["jitter"].items()})
+    ref = g["out"]
+    assert sorted(out.keys()) == sorted(ref.keys())
+    assert torch.equal(out["mask"].cpu().to(torch.uint8), ref["mask"])
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "accumulation_coarse",
+              "accumulation_fine", "weights_coarse", "weights_fine", "diff", "tint", "roughness"):
+        assert max_abs(out[k].detach().cpu(), ref[k]) <= TOL, k
+    for k in ("pred_normals_coarse", "pred_normals_fine", "n_dot_d_coarse", "n_dot_d_fine"):
+        assert max_abs(out[k].detach().cpu(), ref[k]) <= TOL_UNIT, k
+    for lvl in ("coarse", "fine"):
+        e = (out[f"normals_{lvl}"].cpu() - ref[f"normals_{lvl}"]).abs()
+        assert float(e.mean()) <= 1e-3 and float(e.flatten().quantile(0.99)) <= 5e-3, lvl
+    # the analytic normals are a detached loss target in both pipelines (checked above within their conditioning):
+    # give the loss the reference's constant so that the gradient comparison sees the same target
+    checked = dict(out)
+    checked["normals_coarse"], checked["normals_fine"] = ref["normals_coarse"].to(dev), ref["normals_fine"].to(dev)
+    losses = model.get_loss_dict(checked, {"image": i["image"].to(dev)})
+    assert sorted(losses) == sorted(g["loss"])
+    for k, v in g["loss"].items():
+        assert abs(float(losses[k].detach()) - float(v)) <= 5e-5 * max(abs(float(v)), 1e-3), k
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    for name, p in model.field.named_parameters():
+        if name not in g["grad"]:
+            assert p.grad is None, name
+            continue
+        a, b = p.grad.cpu().flatten().double(), g["grad"][name].flatten().double()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+        rel = float((a - b).norm() / (b.norm() + 1e-300))
+        # Everything that does not sit below an encoding-consuming layer must agree tightly.  Trunk layers 0..skip see
+        # ReLU flips: the PDF-resampled fine bins of the two pipelines differ by ~1e-6, a few of them are only ulps
+        # wide, their (undamped) high-frequency IPE features differ visibly, and the two layers that consume the
+        # encoding directly (0 and the skip layer) flip a near-zero unit at 2 of the 512 fine samples -- which moves
+        # the gradient of every layer below by ~1-3 % here (per-layer dY is otherwise identical to 2e-6).
+        skip = 4
+        below = name.startswith("mlp_base.layers.") and int(name.split(".")[2]) <= skip
+        if below:
+            assert cos >= 0.999 and rel <= 5e-2, f"{name}: cos {cos:.6f} rel-L2 {rel:.3e}"
+        else:
+            assert rel <= 2e-4, f"{name}: rel-L2 {rel:.3e}"

@@ -86,3 +86,29 @@ def test_param_count_matches_reference_default():
     fs = cpu_ref.FieldSpec()
     P = cpu_ref.init_params(fs)
     assert sum(v.numel() for v in P.values()) == 618513
+
+
+def test_train_step_matches_reference():
+    """One whole training step of the REFERENCE (get_outputs in train mode -> its own get_loss_dict -> backward,
+    tests/golden/trainstep_l8_w64.npz): the oracle's outputs, its restated loss terms and autograd's gradients
+    through the oracle must reproduce the reference's."""
+    meta, g = load_golden("trainstep_l8_w64")
+    fs, ms = field_spec_from_meta(meta), model_spec_from_meta(meta)
+    i = g["in"]
+    P = {k: v.clone().requires_grad_(True) for k, v in g["param"].items()}
+    out = cpu_ref.get_outputs(P, fs, ms, i["origins"], i["directions"], i["pixel_area"], i["nears"], i["fars"],
+                              training=True, jitter=g["jitter"])
+    assert torch.equal(out["mask"].to(torch.uint8), g["out"]["mask"]) and int(out["mask"].sum()) == meta["M"] > 0
+    for k, v in g["out"].items():
+        if k != "mask":
+            assert max_abs(out[k].detach(), v) <= (2e-6 if not k.startswith("depth") else 1e-5), k
+    assert meta["loss_coefficients"] == pytest.approx(cpu_ref.LOSS_COEFFICIENTS)
+    losses = cpu_ref.loss_dict(out, i["image"], meta["loss_coefficients"])
+    assert sorted(losses) == sorted(g["loss"])
+    for k, v in g["loss"].items():
+        assert abs(float(losses[k].detach()) - float(v)) <= 2e-6 * max(1.0, abs(float(v))), k
+    sum(losses.values()).backward()
+    assert sorted(k for k, p in P.items() if p.grad is not None) == sorted(g["grad"])
+    for k, gr in g["grad"].items():
+        scale = float(gr.abs().max())
+        assert max_abs(P[k].grad, gr) <= 2e-5 * scale + 1e-10, k
