@@ -94,7 +94,7 @@ def train_leg(pkg, args, dev, rank, world, dist, share):
     """Secondary measurement of the default run: BASELINE configs[2]/[4], one full training step per rank (forward,
     twelve loss terms, backward, ONE flat gradient all-reduce over RCCL when N > 1, fused RAdam), timed with the same
     barrier + synchronize + max-over-ranks bracket.  Reported as `train_step` next to the headline; never `value`."""
-    from oracle.cpu_ref import synthetic_rays  # input generator only
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
     from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, train_step
 
     R = args.rays
@@ -169,7 +169,7 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     import reflect_sampling_nerf_amd as pkg
-    from oracle.cpu_ref import synthetic_rays  # input generator only (data, not arithmetic)
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
     from reflect_sampling_nerf_amd import ops
     from reflect_sampling_nerf_amd._abi import RSN_SPACING_UNIFORM
 

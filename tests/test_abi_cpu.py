@@ -84,3 +84,21 @@ def test_config_fields_and_train_mode_is_loud():
     model.eval()
     with pytest.raises(pkg.RsnError):  # CPU tensors: there is no CPU fallback
         model.get_outputs(rb)
+
+
+def test_bench_input_generator_equals_the_oracles():
+    """bench.py draws its rays from the package (the product path never imports oracle/); same rays as the tests'."""
+    from oracle import cpu_ref
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
+
+    for a, b in zip(synthetic_rays(37, seed=5), cpu_ref.synthetic_rays(37, seed=5)):
+        assert torch.equal(a, b)
+    import ast
+
+    tree = ast.parse(open(os.path.join(REPO, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            mods = [node.module or ""] if isinstance(node, ast.ImportFrom) else (
+                [a.name for a in node.names] if isinstance(node, ast.Import) else [])
+            if any(m.split(".")[0] == "oracle" for m in mods):
+                assert fn.name == "cpu_baseline", f"bench.py:{fn.name} imports oracle/ (only the cpu_baseline leg may)"

@@ -37,7 +37,7 @@ def main():
     dbg = handle.rsn_debug_phase_cycles
     dbg.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     dbg.restype = ctypes.c_int
-    from oracle.cpu_ref import synthetic_rays  # input generator only
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
