@@ -18,93 +18,7 @@
 // reflect_sampling_nerf_components.py:52-140 and the nerfstudio primitives N1-N3, N6.
 #include "rsn_mfma.h"
 
-struct FieldArgs {
-  const float* packed;
-  RsnPackedLayout L;
-  int num_layers, skip_layer, width;
-  float density_bias;
-  float freqs[RSN_NUM_FREQS];
-  int mode;
-  int n_rays;          // rays (frustum / inf) or points (gauss)
-  const int* n_dev;    // optional device-side ray count
-  int S;               // samples per ray (1 for inf / gauss)
-  const float* origins;
-  const float* directions;
-  const float* pixel_area;
-  const float* bins;
-  const float* sqradius;
-  const float* means;
-  const float* cov_diag;
-  const float* view_dirs;
-  rsn_field_outputs out;
-  float* embedding;
-  const float* emb_in;        // RSN_MODE_EMB: [N,W] embedding (post-ReLU trunk output) supplied by the caller
-  const float* rough_in;      // RSN_MODE_EMB: optional explicit roughness for the SH attenuation (get_mid's argument)
-  rsn_field_saved saved;      // training: activations kept for the backward pass (all NULL in eval)
-  long long act_stride;       // floats between consecutive layers in saved.act (= n_points_max * W)
-};
-
-// Conical frustum -> Gaussian (nerfstudio conical_frustum_to_gaussian / compute_3d_gaussian, N3),
-// followed by the reference's contraction (reflect_sampling_nerf_field.py:98-119).  Only the diagonal
-// of J Sigma J is consumed downstream (N2), so only that is formed.
-__device__ __forceinline__ void frustum_to_contracted(const float o[3], const float d[3], float pa, float t0, float t1,
-                                                      float mean_c[3], float var_c[3]) {
-  const float radius = sqrtf(pa) / 1.7724538509055159f;
-  const float mu = (t0 + t1) / 2.0f;
-  const float hw = (t1 - t0) / 2.0f;
-  const float hw2 = hw * hw, mu2 = mu * mu;
-  const float den = 3.0f * mu2 + hw2;
-  const float tmean = mu + (2.0f * mu * hw2) / den;
-  float mean[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) mean[c] = o[c] + d[c] * tmean;
-  const float hw4 = hw2 * hw2;
-  const float var_t = hw2 / 3.0f - 0.26666666666666666f * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
-  const float var_r =
-      (radius * radius) * (mu2 / 4.0f + 0.4166666666666667f * hw2 - (0.26666666666666666f * hw4) / den);
-  const float dmag = fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f);
-  // Sigma = var_t d d^T + var_r (I - d (d/dmag)^T)
-  float S[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-      S[i][j] = var_t * (d[i] * d[j]) + var_r * ((i == j ? 1.0f : 0.0f) - d[i] * (d[j] / dmag));
-  // contraction
-  const float n2 = mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2];
-  const float n = sqrtf(n2);
-  if (n > 1.0f) {
-    const float sc = (2.0f * n - 1.0f) / n2;
-    float J[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float eye = (i == j) ? 1.0f : 0.0f;
-        const float outer = mean[i] * mean[j] / n2;
-        J[i][j] = ((2.0f * n - 2.0f) * (eye - outer) + eye) / n2;
-      }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) mean_c[c] = sc * mean[c];
-    // diag(J S J)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const float js = J[i][0] * S[0][b] + J[i][1] * S[1][b] + J[i][2] * S[2][b];
-        acc += js * J[b][i];
-      }
-      var_c[i] = fmaxf(acc, 0.0f);
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      mean_c[c] = mean[c];
-      var_c[c] = fmaxf(S[c][c], 0.0f);
-    }
-  }
-}
+#include "rsn_field_common.h"
 
 // Optional per-phase cycle accounting (debug builds only: tools/phase_report.py compiles a second library with
 // -DRSN_PHASE_TIMERS).  Wave 0 of every workgroup sums shader-clock deltas per phase; never part of librsn_hip.so.
@@ -140,7 +54,6 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  const int m = lane & 31, h = lane >> 5;
   float4* X = smem + wid * WAVE_F4 + lane;
   float4* AUX = X + XITS * 64;
   float* Xf = reinterpret_cast<float*>(X);
@@ -161,6 +74,11 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long p0 = tile * 128 + wid * 32;
     if (p0 >= n_points) continue;  // wave-uniform; waves never synchronise with each other
+    // an opaque copy of the lane id per tile: per-lane weight / output addresses are then not loop-invariant, so hipcc
+    // cannot hoist dozens of them out of the persistent tile loop and spill them to scratch
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int m = ln & 31, h = ln >> 5;
     RSN_T(11);
     const long long p = p0 + m;
     const bool valid = p < n_points;
@@ -170,7 +88,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     bool has_cov = true, has_dir = true;
     float4 wbh[NB + 1];  // first weight fragment of the bottleneck+heads GEMM
     if (a.mode == RSN_MODE_EMB) {
-      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, lane);
+      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, ln);
       // granular Field API: heads / mid MLP on a caller-supplied embedding (field.py:139-186)
       has_dir = a.view_dirs != nullptr;
 #pragma unroll
@@ -263,22 +181,22 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     {
       f32x16 acc[NB];
       float4 wpre[NB];  // first weight fragment of the next GEMM, fetched ahead of the epilogue in front of it
-      pre_mode<MODE, NB>(wpre, pk + a.L.w_enc0, lane);
+      pre_mode<MODE, NB>(wpre, pk + a.L.w_enc0, ln);
       init_acc<NB>(acc, pk + a.L.b[0], h);
       RSN_T(1);
-      gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc0, pk + a.L.h_enc0, X, RSN_ENC_ITS, lane);
+      gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc0, pk + a.L.h_enc0, X, RSN_ENC_ITS, ln);
       RSN_T(2);
 #pragma unroll 1
       for (int l = 1; l < a.num_layers; ++l) {
-        pre_mode<MODE, NB>(wpre, pk + a.L.w_x[l], lane);
+        pre_mode<MODE, NB>(wpre, pk + a.L.w_x[l], ln);
         // ReLU between layers; the accumulators restart from layer l's bias
         store_act_init<NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (l - 1) * a.act_stride + pc * W : nullptr,
                                  h, pk + a.L.b[l]);
         RSN_T(3);
-        gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, lane);
+        gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, ln);
         RSN_T(4);
         if (l == a.skip_layer) {
-          pre_mode<MODE, NB>(wpre, pk + a.L.w_enc_skip, lane);
+          pre_mode<MODE, NB>(wpre, pk + a.L.w_enc_skip, ln);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             X[it * 64] = make_float4(st0[4 * it], st0[4 * it + 1], st0[4 * it + 2], st0[4 * it + 3]);
@@ -287,12 +205,12 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           }
           X[12 * 64] = st3;
           if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc_skip, pk + a.L.h_enc_skip, X, RSN_ENC_ITS, lane);
+          gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc_skip, pk + a.L.h_enc_skip, X, RSN_ENC_ITS, ln);
           RSN_T(2);
         }
       }
       // out_activation = ReLU
-      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, lane);
+      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, ln);
       store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (a.num_layers - 1) * a.act_stride + pc * W : nullptr, h);
       RSN_T(3);
     }
@@ -310,9 +228,9 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       f32x16 acc[NB + 1];
       init_acc<NB + 1>(acc, pk + a.L.b_bh, h);
       RSN_T(1);
-      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + a.L.w_bh, pk + a.L.h_bh, X, NB * 4, lane);
+      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + a.L.w_bh, pk + a.L.h_bh, X, NB * 4, ln);
       RSN_T(5);
-      pre_mode<MODE, 4>(wmid, pk + a.L.w_mid_sh, lane);
+      pre_mode<MODE, 4>(wmid, pk + a.L.w_mid_sh, ln);
       const float r0 = acc[NB][0], r1 = acc[NB][1], r2 = acc[NB][2], r3 = acc[NB][3];
       const float r4 = acc[NB][4], r5 = acc[NB][5], r6 = acc[NB][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
@@ -385,12 +303,12 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       init_acc<4>(accm, pk + a.L.b_mid, h);
       RSN_T(1);
       float4 wmx[4];
-      pre_mode<MODE, 4>(wmx, pk + a.L.w_mid_x, lane);
-      gemm_mode_run<MODE, 4>(accm, wmid, pk + a.L.w_mid_sh, pk + a.L.h_mid_sh, AUX, RSN_SH_ITS, lane);
+      pre_mode<MODE, 4>(wmx, pk + a.L.w_mid_x, ln);
+      gemm_mode_run<MODE, 4>(accm, wmid, pk + a.L.w_mid_sh, pk + a.L.h_mid_sh, AUX, RSN_SH_ITS, ln);
       RSN_T(7);
-      gemm_mode_run<MODE, 4>(accm, wmx, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, lane);
+      gemm_mode_run<MODE, 4>(accm, wmx, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, ln);
       RSN_T(8);
-      pre_mode<MODE, 1>(wrgb, pk + a.L.w_rgb, lane);
+      pre_mode<MODE, 1>(wrgb, pk + a.L.w_rgb, ln);
       store_act<4, 4, true>(accm, X, (TRAIN && a.saved.hid && valid) ? a.saved.hid + pc * 128 : nullptr, h);
       RSN_T(3);
     }
@@ -398,7 +316,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       f32x16 accr[1];
       init_acc<1>(accr, pk + a.L.b_rgb, h);
       RSN_T(1);
-      gemm_mode_run<MODE, 1>(accr, wrgb, pk + a.L.w_rgb, pk + a.L.h_rgb, X, 16, lane);
+      gemm_mode_run<MODE, 1>(accr, wrgb, pk + a.L.w_rgb, pk + a.L.h_rgb, X, 16, ln);
       RSN_T(9);
       if (h == 1 && valid) {
         const float m0 = sigmoid_f(accr[0][0]);
@@ -440,16 +358,16 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       zero_acc<4>(eacc);
 #pragma unroll 1
       for (int l = a.num_layers - 1; l >= 1; --l) {
-        if (l == a.skip_layer) gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, lane);
+        if (l == a.skip_layer) gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, ln);
         float4 mk[NB * 4];
         load_mask<NB>(mk, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[NB];
         zero_acc<NB>(acc);
-        gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, lane);
+        gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
         store_masked_pre<NB>(acc, X, mk, h);
       }
-      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, lane);
+      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, ln);
       store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
       float nrm[3];
 #pragma unroll 1
@@ -519,6 +437,10 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
   const bool train = a.saved.act != nullptr || a.saved.enc != nullptr || a.saved.heads != nullptr;
   a.act_stride = n_points * (long long)d->width;
   const int mode = d->mma_mode;
+  if (!train && mode == RSN_MMA_BF16) {  // plain bf16 operands: its own kernel, two workgroups per CU
+    const long long g2 = n_tiles < 2LL * cus ? n_tiles : 2LL * cus;
+    return rsn_launch_field_bf16(d->width, g2, st, a);
+  }
 #define RSN_LAUNCH(NBV)                                                                                          \
   do {                                                                                                           \
     if (train && mode == RSN_MMA_BF16X6)                                                                        \
@@ -529,8 +451,6 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
       hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
     else if (mode == RSN_MMA_BF16X3)                                                                            \
       hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
-    else if (mode == RSN_MMA_BF16)                                                                              \
-      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
     else                                                                                                         \
       hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
   } while (0)

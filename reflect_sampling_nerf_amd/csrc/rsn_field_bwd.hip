@@ -111,7 +111,6 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  const int m = lane & 31, h = lane >> 5;
   float4* X = smem + wid * WAVE_F4 + lane;  // its XITS.. spill into the SH region (contiguous): NB*4+4 <= XITS+5
   float* Xf = reinterpret_cast<float*>(X);
 
@@ -128,6 +127,10 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long p0 = tile * 128 + wid * 32;
     if (p0 >= n_points) continue;
+    // opaque per-tile copy of the lane id: keeps hipcc from hoisting (and spilling) per-lane addresses out of the loop
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int m = ln & 31, h = ln >> 5;
     const long long p = p0 + m;
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
@@ -166,14 +169,14 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[4];
       zero_acc<4>(acc);
-      gemm_mode<MODE, 4>(acc, pk + a.L.wT_rgb, pk + a.L.hT_rgb, X, 4, lane);
+      gemm_mode<MODE, 4>(acc, pk + a.L.wT_rgb, pk + a.L.hT_rgb, X, 4, ln);
       store_masked_pre<4>(acc, X, mk, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + a.L.wT_mid_x, pk + a.L.hT_mid_x, X, 16, lane);
+      gemm_mode<MODE, NB>(acc, pk + a.L.wT_mid_x, pk + a.L.hT_mid_x, X, 16, ln);
       store_act<NB, NB, false>(acc, X, (valid && a.gout.d_bott) ? a.gout.d_bott + pc * W : nullptr, h);
     }
     // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + a.L.wT_bh, pk + a.L.hT_bh, X, NB * 4 + 4, lane);
+      gemm_mode<MODE, NB>(acc, pk + a.L.wT_bh, pk + a.L.hT_bh, X, NB * 4 + 4, ln);
       store_masked_pre<NB>(acc, X, mk, h, valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
@@ -241,18 +244,18 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
 #pragma unroll 1
     for (int l = a.num_layers - 1; l >= 1; --l) {
       if (a.need_input_grad && l == a.skip_layer)
-        gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, lane);
+        gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, ln);
       float4 mk[NB * 4];
       load_mask<NB>(mk, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, lane);
+      gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
       store_masked_pre<NB>(acc, X, mk, h, valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
     if (a.need_input_grad) {
-      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, lane);
+      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, ln);
       store_act<4, 4, false>(eacc, X);  // d loss / d encoded input, slot order
       const float* encp = a.saved.enc + pc * RSN_K_ENC_PAD;
       float dvar[3];
