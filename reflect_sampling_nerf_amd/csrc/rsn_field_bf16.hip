@@ -22,6 +22,26 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
   return o;
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+// Two fp32 -> one dword of two bf16 (v_cvt_pk_bf16_f32), optionally ReLU'd.  ReLU on packed bf16: as signed 16-bit
+// integers negative floats (and -0) are negative, so one v_pk_max_i16 with 0 per PAIR of values does it -- after the
+// rounding, which commutes with ReLU (rounding is sign-symmetric and monotone).  The fp32 form costs hipcc two
+// v_max (canonicalise + max) per value: a quarter of this kernel's VALU work.
+template <bool RELU>
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+  const float2v f = {a, b};
+  short2v s = __builtin_bit_cast(short2v, __builtin_convertvector(f, bf16x2));
+  if (RELU) {
+    const short2v z = {0, 0};
+    s = __builtin_elementwise_max(s, z);
+  }
+  return __builtin_bit_cast(unsigned int, s);
+}
+
 // acc -> slab: blocks 0..NBS-1; K=16 step nb*2 + qp holds accumulator registers 8qp..8qp+7 of block nb
 template <int NBO, int NBS, bool RELU>
 __device__ __forceinline__ void store_h(const f32x16 (&acc)[NBO], bf16x8* xh) {
@@ -29,10 +49,10 @@ __device__ __forceinline__ void store_h(const f32x16 (&acc)[NBO], bf16x8* xh) {
   for (int nb = 0; nb < NBS; ++nb)
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp) {
-      float v[8];
+      uint4v w;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = RELU ? relu_f(acc[nb][8 * qp + e]) : acc[nb][8 * qp + e];
-      xh[(nb * 2 + qp) * 64] = pack8(v);
+      for (int e = 0; e < 4; ++e) w[e] = pack2<RELU>(acc[nb][8 * qp + 2 * e], acc[nb][8 * qp + 2 * e + 1]);
+      xh[(nb * 2 + qp) * 64] = __builtin_bit_cast(bf16x8, w);
     }
 }
 
