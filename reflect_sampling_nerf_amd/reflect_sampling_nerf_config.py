@@ -49,37 +49,32 @@ class ReflectSamplingNeRFPipelineConfig(VanillaPipelineConfig):
     _target: Type = field(default_factory=lambda: ReflectSamplingNeRFPipeline)
 
 
+def _group(optimizer_cls, lr_final: float, max_steps: int):
+    """One optimiser group: lr 1e-3 / eps 1e-15 with exponential decay to lr_final (reference config.py:44-59)."""
+    return {"optimizer": optimizer_cls(lr=1e-3, eps=1e-15),
+            "scheduler": ExponentialDecaySchedulerConfig(lr_final=lr_final, max_steps=max_steps)}
+
+
+def method_config() -> TrainerConfig:
+    """The reference's trainer settings (config.py:28-61) around the MI355X Model; built in steps rather than as one
+    literal so that each departure from the reference is visible: mixed precision off, this package's targets."""
+    rays = 1 << 10
+    data = ReflectSamplingNeRFDataManagerConfig(dataparser=BlenderDataParserConfig(), train_num_rays_per_batch=rays,
+                                                eval_num_rays_per_batch=rays)
+    pipeline = ReflectSamplingNeRFPipelineConfig(datamanager=data,
+                                                 model=ReflectSamplingNeRFModelConfig(eval_num_rays_per_chunk=rays))
+    groups = {
+        "fields": _group(RAdamOptimizerConfig, 1e-4, 50000),  # the only group get_param_groups() returns
+        "proposal_networks": _group(AdamOptimizerConfig, 1e-4, 200000),
+        "camera_opt": _group(AdamOptimizerConfig, 1e-4, 5000),
+    }
+    return TrainerConfig(method_name="reflect-sampling-nerf", pipeline=pipeline, optimizers=groups,
+                         max_num_iterations=100000, steps_per_eval_batch=100, steps_per_save=1000,
+                         mixed_precision=False,  # the HIP path computes in fp32 (the reference enables fp16 autocast)
+                         viewer=ViewerConfig(num_rays_per_chunk=rays), vis="viewer")
+
+
 reflect_sampling_nerf = MethodSpecification(
-    config=TrainerConfig(
-        method_name="reflect-sampling-nerf",
-        steps_per_eval_batch=100,
-        steps_per_save=1000,
-        max_num_iterations=100000,
-        mixed_precision=False,  # the HIP path is fp32 (the reference enables fp16 autocast, config.py:33)
-        pipeline=ReflectSamplingNeRFPipelineConfig(
-            datamanager=ReflectSamplingNeRFDataManagerConfig(
-                dataparser=BlenderDataParserConfig(),
-                train_num_rays_per_batch=1024,
-                eval_num_rays_per_batch=1024,
-            ),
-            model=ReflectSamplingNeRFModelConfig(eval_num_rays_per_chunk=1 << 10),
-        ),
-        optimizers={
-            "proposal_networks": {
-                "optimizer": AdamOptimizerConfig(lr=1e-3, eps=1e-15),
-                "scheduler": ExponentialDecaySchedulerConfig(lr_final=0.0001, max_steps=200000),
-            },
-            "fields": {
-                "optimizer": RAdamOptimizerConfig(lr=1e-3, eps=1e-15),
-                "scheduler": ExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=50000),
-            },
-            "camera_opt": {
-                "optimizer": AdamOptimizerConfig(lr=1e-3, eps=1e-15),
-                "scheduler": ExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=5000),
-            },
-        },
-        viewer=ViewerConfig(num_rays_per_chunk=1 << 10),
-        vis="viewer",
-    ),
+    config=method_config(),
     description="reflect-sampling-nerf on MI355X (HIP kernels behind the Nerfstudio Model/Field surface).",
 )
