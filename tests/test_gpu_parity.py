@@ -879,3 +879,96 @@ def test_train_step_against_reference_fixture(dev):
             assert cos >= 0.999 and rel <= 5e-2, f"{name}: cos {cos:.6f} rel-L2 {rel:.3e}"
         else:
             assert rel <= 2e-4, f"{name}: rel-L2 {rel:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE configurations
+def test_baseline_config0_level_matches_oracle(dev):
+    """BASELINE configs[0] exactly: 1024 rays x 64 samples, 4-layer 128-wide trunk, random-init weights, one level of
+    the Field.get_outputs plumbing (forward + composite) against the CPU oracle."""
+    R, S = 1024, 64
+    fld, P, fs = make_field(4, 128, dev, seed=0)
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=0)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    with torch.no_grad():
+        ref = cpu_ref.render_level(P, fs, o, d, pa, nears, fars, S)
+    sb, eb = ops.sample_spaced(R, None, S, RSN_SPACING_UNIFORM, 1.0, nears.reshape(R).to(dev), fars.reshape(R).to(dev),
+                               None)
+    lv = fld.evaluate_frustums(o.to(dev), d.to(dev), pa.reshape(R).to(dev), eb)
+    c = ops.composite(R, None, S, 1, ops.RSN_COMP_EVAL | ops.RSN_COMP_CLIP_RGB, lv["sigma"], eb, lv["color"])
+    assert max_abs(c["rgb"].cpu(), ref["rgb"]) <= TOL
+    assert max_abs(c["accumulation"].cpu(), ref["accumulation"][..., 0]) <= TOL
+    assert max_abs(c["weights"].cpu(), ref["weights"][..., 0]) <= 1e-5
+
+
+def test_baseline_config2_training_step_properties(dev):
+    """BASELINE configs[2] size (4096 rays x (64 coarse + 128 fine) + reflect 64 + 64, 8 x 256, forward + backward):
+    size-independent properties of whole training steps instead of an oracle run."""
+    from reflect_sampling_nerf_amd.parallel import train_step
+
+    R = 4096
+    torch.manual_seed(0)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=64, num_importance_samples=128)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 2.0
+    model.to(dev).train()
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=0)
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev),
+                       nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
+    batch = {"image": torch.rand(R, 3, generator=torch.Generator().manual_seed(1)).to(dev)}
+    params = model.get_param_groups()["fields"]
+    opt = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15)
+    # one forward/backward by hand: every parameter except the never-evaluated field_output_low gets a finite gradient
+    out = model(rb)
+    assert int(out["mask"].sum()) > 0, "the reflect branch must be exercised"
+    loss = sum(model.get_loss_dict(out, batch).values())
+    loss.backward()
+    for name, p in model.field.named_parameters():
+        if "field_output_low" in name:
+            assert p.grad is None
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0.0, name
+    w = out["weights_fine"][..., 0]
+    assert float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-5
+    assert float((out["normals_fine"].norm(dim=-1) - 1).abs().max()) <= 1e-4
+    # the same step twice from the same state: equal up to the order of the fp32 atomics in the weight-gradient flush
+    g1 = {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(123)
+    l1 = float(sum(model.get_loss_dict(model(rb), batch).values()).detach())
+    torch.manual_seed(123)
+    out2 = model(rb)
+    loss2 = sum(model.get_loss_dict(out2, batch).values())
+    assert abs(float(loss2.detach()) - l1) <= 1e-6 * abs(l1)
+    # a few optimiser steps move every trained tensor and keep everything finite
+    before = [p.detach().clone() for p in params]
+    losses = [float(train_step(model, rb, batch, opt, None, 100 + k)) for k in range(3)]
+    assert all(x == x and abs(x) < float("inf") for x in losses)
+    moved = [not torch.equal(a, b.detach()) for a, b in zip(before, params)]
+    assert sum(moved) >= len(params) - 2 and all(bool(torch.isfinite(p).all()) for p in params)
+    assert g1  # gradients existed
+
+
+def test_baseline_config3_bf16_properties(dev):
+    """BASELINE configs[3] size (16384 rays x 192 samples, bf16 MFMA hidden GEMMs): properties + a slice against the
+    exact-fp32 kernel within the bf16 tolerance."""
+    R, S = 16384, 192
+    fld, _, _ = make_field(8, 256, dev, seed=0, bias_shift=1.0)
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=0)
+    o, d, pa = o.to(dev), d.to(dev), pa.reshape(R).to(dev)
+    nears, fars = torch.full((R,), 2.0, device=dev), torch.full((R,), 6.0, device=dev)
+    sb, eb = ops.sample_spaced(R, None, S, RSN_SPACING_UNIFORM, 1.0, nears, fars, None)
+    fld.set_mma_mode("bf16")
+    lv = fld.evaluate_frustums(o, d, pa, eb)
+    c = ops.composite(R, None, S, 1, ops.RSN_COMP_EVAL | ops.RSN_COMP_CLIP_RGB, lv["sigma"], eb, lv["color"])
+    lv2 = fld.evaluate_frustums(o, d, pa, eb)
+    assert torch.equal(lv["color"], lv2["color"]) and torch.equal(lv["sigma"], lv2["sigma"])  # deterministic
+    assert bool(torch.isfinite(lv["color"]).all()) and bool(torch.isfinite(lv["sigma"]).all())
+    w = c["weights"]
+    assert float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-5
+    assert float(c["rgb"].min()) >= 0.0 and float(c["rgb"].max()) <= 1.0
+    fld.set_mma_mode("f32")
+    ref = fld.evaluate_frustums(o[:512], d[:512], pa[:512], eb[:512].contiguous())
+    assert max_abs(lv["color"][:512], ref["color"]) <= 3e-2
+    rel = (lv["sigma"][:512] - ref["sigma"]).abs() / (1.0 + ref["sigma"].abs())
+    assert float(rel.max()) <= 3e-2
