@@ -113,20 +113,26 @@ class _GradAcc:
     def __init__(self, field):
         self.field = field
         dev = next(field.parameters()).device
-        self.g: Dict[str, Tensor] = {n: torch.zeros_like(p) for n, p in field.named_parameters()
-                                     if "field_output_low" not in n}
         W = field.width
-        self.heads_w = torch.zeros(16, W, device=dev)  # rows: 0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint
-        self.heads_b = torch.zeros(16, device=dev)
+        # one flat zero-filled buffer (one fill kernel per step), viewed per parameter + the two heads blocks
+        named = [(n, p) for n, p in field.named_parameters() if "field_output_low" not in n]
+        sizes = [p.numel() for _, p in named] + [16 * W, 16]
+        flat = torch.zeros(sum(sizes), device=dev)
+        views = flat.split(sizes)
+        self.g: Dict[str, Tensor] = {n: v.view_as(p) for (n, p), v in zip(named, views)}
+        self.heads_w = views[-2].view(16, W)  # rows: 0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint
+        self.heads_b = views[-1]
         if not hasattr(field, "_enc_col_map") or field._enc_col_map.device != dev:
             field._enc_col_map = torch.tensor(enc_slot_columns(), dtype=torch.int32, device=dev)
             field._sh_col_map = torch.tensor(sh_slot_columns(), dtype=torch.int32, device=dev)
 
     def finish(self) -> Dict[str, Tensor]:
+        dst, src = [], []
         for name, lo, hi in (("density", 0, 1), ("normals", 1, 4), ("diff", 4, 7), ("roughness", 8, 9),
                              ("tint", 12, 15)):
-            self.g[f"field_output_{name}.net.weight"] += self.heads_w[lo:hi]
-            self.g[f"field_output_{name}.net.bias"] += self.heads_b[lo:hi]
+            dst += [self.g[f"field_output_{name}.net.weight"], self.g[f"field_output_{name}.net.bias"]]
+            src += [self.heads_w[lo:hi], self.heads_b[lo:hi]]
+        torch._foreach_copy_(dst, src)  # the head tensors received nothing else: a copy, in one multi-tensor launch
         return self.g
 
 
