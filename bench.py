@@ -50,7 +50,7 @@ def parse():
                          "fp32 emulation by 3-way bf16 splits (fp32-equivalent results); bf16x3 = reduced precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
-    ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample (~10 s of CPU work)")
     return ap.parse_args()
 
 
