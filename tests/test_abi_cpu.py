@@ -102,3 +102,34 @@ def test_bench_input_generator_equals_the_oracles():
                 [a.name for a in node.names] if isinstance(node, ast.Import) else [])
             if any(m.split(".")[0] == "oracle" for m in mods):
                 assert fn.name == "cpu_baseline", f"bench.py:{fn.name} imports oracle/ (only the cpu_baseline leg may)"
+
+
+def test_slot_maps_are_permutations_of_the_reference_columns():
+    """Host tables of the training graph: the kernel's slot order of the 99 encoded inputs / 34 SH inputs must hit every
+    reference column exactly once (padding slots map to -1)."""
+    from reflect_sampling_nerf_amd.train_graph import ENC_SLOTS, SH_SLOTS, enc_slot_columns, sh_slot_columns
+
+    enc = enc_slot_columns()
+    assert len(enc) == ENC_SLOTS == 104 and sorted(c for c in enc if c >= 0) == list(range(99))
+    sh = sh_slot_columns()
+    assert len(sh) == SH_SLOTS == 40 and sorted(c for c in sh if c >= 0) == list(range(34))
+
+
+def test_config_defaults_match_the_reference_run():
+    """Loss coefficients and sample counts of the default ModelConfig against what the reference's own config held when
+    the training-step fixture was generated (meta of tests/golden/trainstep_l8_w64.npz)."""
+    meta, _ = load_golden("trainstep_l8_w64")
+    cfg = pkg.ReflectSamplingNeRFModelConfig()
+    assert dict(cfg.loss_coefficients) == pytest.approx(meta["loss_coefficients"])
+    assert (cfg.num_coarse_samples, cfg.num_importance_samples, cfg.num_reflect_coarse_samples,
+            cfg.num_reflect_importance_samples) == (128, 128, 64, 64)  # model.py:46-54
+
+
+def test_exponential_decay_lr_schedule():
+    """config.py:50-53: lr 1e-3 decaying log-linearly to 1e-4 at step 50 000, constant afterwards."""
+    from reflect_sampling_nerf_amd.train_ops import exponential_decay_lr
+
+    assert exponential_decay_lr(0) == pytest.approx(1e-3)
+    assert exponential_decay_lr(25000) == pytest.approx((1e-3 * 1e-4) ** 0.5)
+    assert exponential_decay_lr(50000) == pytest.approx(1e-4)
+    assert exponential_decay_lr(10 ** 6) == pytest.approx(1e-4)
