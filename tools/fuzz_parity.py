@@ -18,6 +18,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--train", action="store_true", help="training mode: forward with shared jitter + backward of the "
+                    "reference loss; gradients compared in direction (cosine) and None-pattern")
     args = ap.parse_args()
     import reflect_sampling_nerf_amd as pkg
     from oracle import cpu_ref
@@ -58,11 +60,45 @@ def main():
             o = o * 0.1
             nears, fars = torch.full((R, 1), 0.05), torch.full((R, 1), 1.5)
         fs, ms = cpu_ref.FieldSpec(num_layers=layers, width=width), cpu_ref.ModelSpec(*samples)
-        with torch.no_grad():
-            ref = cpu_ref.get_outputs(P, fs, ms, o, d, pa, nears, fars, training=False)
         rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev), nears=nears.to(dev),
                            fars=fars.to(dev))
-        out = model._get_outputs_eval(rb) if hasattr(model, "_get_outputs_eval") else model(rb)
+        grad_note = ""
+        if args.train:
+            g = torch.Generator().manual_seed(case)
+            jit = {"coarse": torch.rand(R, samples[0] + 1, generator=g), "fine": torch.rand(R, samples[1] + 1, generator=g),
+                   "reflect_coarse": torch.rand(R, samples[2] + 1, generator=g),
+                   "reflect_fine": torch.rand(R, samples[3] + 1, generator=g)}
+            image = torch.rand(R, 3, generator=g)
+            Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            ref = cpu_ref.get_outputs(Pg, fs, ms, o, d, pa, nears, fars, training=True, jitter=jit)
+            sum(cpu_ref.loss_dict(ref, image).values()).backward()
+            model.train()
+            mk = ref["mask"]
+            jg = dict(jit, reflect_coarse=jit["reflect_coarse"][mk], reflect_fine=jit["reflect_fine"][mk])
+            out = model._get_outputs_train(rb, jitter={k: v.to(dev) for k, v in jg.items()})
+            chk = dict(out)
+            chk["normals_coarse"], chk["normals_fine"] = ref["normals_coarse"].detach().to(dev), ref["normals_fine"].detach().to(dev)
+            sum(model.get_loss_dict(chk, {"image": image.to(dev)}).values()).backward()
+            worst_cos, pat = 1.0, True
+            for name, p in model.field.named_parameters():
+                gr = Pg[name].grad
+                if gr is None or float(gr.abs().max()) == 0.0:
+                    pat &= p.grad is None or float(p.grad.abs().max()) <= 1e-12
+                    continue
+                if p.grad is None or not bool(torch.isfinite(p.grad).all()):
+                    pat = False
+                    continue
+                a, b = p.grad.cpu().flatten().double(), gr.flatten().double()
+                worst_cos = min(worst_cos, float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)))
+            grad_note = " grad-pattern=%s min-cos=%.5f" % (pat, worst_cos)
+            ref = {k: v.detach() for k, v in ref.items()}
+            out = {k: v.detach() for k, v in out.items()}
+            if not pat or worst_cos < 0.99:
+                grad_note += " GRAD-VIOLATION"
+        else:
+            with torch.no_grad():
+                ref = cpu_ref.get_outputs(P, fs, ms, o, d, pa, nears, fars, training=False)
+            out = model._get_outputs_eval(rb) if hasattr(model, "_get_outputs_eval") else model(rb)
         worst, worst_key = 0.0, ""
         ok = set(out.keys()) == set(ref.keys())
         flips = int((out["mask"].cpu() != ref["mask"]).sum())
@@ -74,10 +110,10 @@ def main():
                     e = float("inf")
                 if e > worst:
                     worst, worst_key = e, k
-        status = "ok" if (ok and flips == 0 and worst <= 1e-4) else "VIOLATION"
+        status = "ok" if (ok and flips == 0 and worst <= 1e-4 and "GRAD-VIOLATION" not in grad_note) else "VIOLATION"
         bad += status != "ok"
         print("case %2d L=%d W=%3d S=%-16s R=%3d bias=%5.1f %-18s M=%3d keys=%s flips=%d worst %.2e %s  %s" %
-              (case, layers, width, samples, R, bias, kind, int(ref["mask"].sum()), ok, flips, worst, worst_key, status),
+              (case, layers, width, samples, R, bias, kind, int(ref["mask"].sum()), ok, flips, worst, worst_key + grad_note, status),
               flush=True)
     print("violations:", bad)
     sys.exit(1 if bad else 0)
