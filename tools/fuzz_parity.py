@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mma", default="f32", help="f32 | bf16x6 (the fp32-emulating mode must meet the same bounds)")
     ap.add_argument("--train", action="store_true", help="training mode: forward with shared jitter + backward of the "
                     "reference loss; gradients compared in direction (cosine) and None-pattern")
     args = ap.parse_args()
@@ -46,6 +47,7 @@ def main():
             model.field.field_output_density.net.bias += bias
         P = {k: v.detach().clone() for k, v in model.field.state_dict().items()}
         model.to(dev).eval()
+        model.field.set_mma_mode(args.mma)
         o, d, pa = cpu_ref.synthetic_rays(R, seed=1000 + case)
         nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
         if kind == "unnormalised_dirs":
