@@ -338,8 +338,9 @@ def main():
                     "unit": "TFLOP/s",
                     "frac": achieved * mult / peak,
                     "traffic": traffic,
-                    "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), PMC passes "
-                                    "of tools/profile_round.sh, latest profiles/*_summary.json",
+                    "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), separate --pmc "
+                                    "passes of tools/profile_round.sh; newest profiles/*_summary.json taken on this "
+                                    "kernel instantiation and workload size (null if none)",
                     "kernel_ms": kms,
                     "algorithmic_flop_per_launch": flop,
                 }
