@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- rays/s of the reflect-sampling-nerf hot path on MI355X.
+"""bench.py -- rays/s of the reflect-sampling-nerf training step on MI355X (BASELINE.json `metric`:
+"rays/sec (train step) at 4096 rays x 128 samples, 1/2/4/8 MI355X").
 
-Workload at N=1 (BASELINE.json configs[1], the configuration the metric is quoted on):
-    4096 rays x 128 samples, 8-layer 256-wide trunk, fp32, fused forward + composite of one
-    sampling level: uniform sampler -> fused field kernel (IPE, trunk, heads, SH, mid MLP, colour)
-    -> per-ray compositing (weights, RGB on white, accumulation, median depth).
-    Synthetic camera-shell rays, random-init weights, inputs resident in HBM.
-With --gpus N every rank renders its own 4096-ray batch (weak scaling; rays are independent, the forward
-path has no data-path collective -- the gradient all-reduce belongs to the training step).
+Headline workload, the SAME at every N (so the driver's 1->2->4->8 curve compares like with like):
+    one optimisation step per rank on 4096 rays -- training-mode get_outputs with the reference's default sample
+    counts (128 coarse + 128 fine + reflect 64 + 64, model.py:46-54; stratified jitter, analytic normals), the eight
+    loss terms of get_loss_dict, backward (dX sweeps + weight gradients), ONE flat gradient all-reduce over RCCL when
+    N > 1 (parallel.FlatGradAllReduce == DDP with find_unused_parameters=True, pipeline.py:72-77), fused RAdam --
+    8-layer 256-wide field, exact fp32, synthetic camera-shell rays, random-init weights, inputs
+    resident in HBM.  Weak scaling: every rank draws its own 4096 rays; `value` = N * 4096 * steps / max-over-ranks
+    wall time between two barrier + synchronize brackets.
 
 One JSON line is printed by rank 0 (contract in the task statement), including
-  roofline     -- the dominant kernel (rsn_field_kernel), MFMA-bound: algorithmic FLOP (1,230,592 per sample,
-                  SURVEY §8(d)) / its average duration, measured live with HIP events on its stream;
-  cpu_baseline -- the CPU oracle (oracle/cpu_ref.py, a port of the reference's PyTorch op sequence) timed on the
-                  host cores on a bounded sample of the same workload.
+  roofline     -- the dominant kernel of the step (the training forward rsn_field_kernel<8,true,0>), MFMA-bound:
+                  algorithmic FLOP of its launches / their summed duration, measured live with HIP events on the
+                  launch stream inside the timed region (ops.KernelTimer);
+  train_step   -- algorithmic FLOP per step (formula + measured reflect-ray count M) and the same per-kernel
+                  figures for the backward sweep and the weight-gradient kernels;
+  cpu_baseline -- the CPU oracle (oracle/cpu_ref.py, a port of the reference's PyTorch op sequence: get_outputs in
+                  training mode + loss + autograd backward) timed on the host cores on a bounded sample;
+  eval_level   -- (N = 1) BASELINE configs[1]: 4096 rays x 128 samples fused forward + composite of one level, with
+                  its own roofline and CPU baseline (the round-1 headline, kept for continuity).
+A stalled or failed step exits NON-ZERO (watchdog: rc 3, exception: rc 4 after printing the error to stderr).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
+import traceback
 
 import torch
 
@@ -27,9 +37,23 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-FLOP_PER_SAMPLE = 1_230_592  # 2 x 615,296 MAC at W=256, L=8
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
+ENC_DIM, SH_DIM, MID_W = 99, 34, 128
+
+
+def algorithmic_macs(layers: int, width: int):
+    """MAC per field point (SURVEY 8(d)).  forward: trunk + bottleneck + mlp_mid + heads (615,296 at 8 x 256);
+    normals: the dX-only sweep through the trunk that Field.get_normals' autograd.grad performs (= trunk MACs);
+    backward: dX through every GEMM whose input carries gradient (the SH part of mlp_mid does not; the encoded input
+    only where pixel_area does: reflect levels and get_inf_color); wgrad: dW = dY^T X of every weight (= forward)."""
+    W, L = width, layers
+    skip = L > 5  # skip_connections=(4,) is live only when layer 4 is not the last (SURVEY F0)
+    trunk = ENC_DIM * W + (L - 1) * W * W + (ENC_DIM * W if skip else 0)
+    fwd = trunk + W * W + (SH_DIM + W) * MID_W + 11 * W + 3 * MID_W
+    bwd = 3 * MID_W + MID_W * W + (W + 11) * W + (L - 1) * W * W
+    return {"forward": fwd, "normals": trunk, "backward": bwd,
+            "backward_input": bwd + ENC_DIM * W * (2 if skip else 1), "wgrad": fwd}
 
 
 def parse():
@@ -38,92 +62,125 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=4096)
-    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--samples", type=int, default=128, help="samples per primary level (coarse and fine)")
+    ap.add_argument("--coarse", type=int, default=0, help="coarse samples if different from --samples (configs[2]: 64)")
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--width", type=int, default=256)
-    ap.add_argument("--workload", default="level", choices=["level", "get_outputs", "train"],
-                    help="level = BASELINE configs[1] (default); get_outputs = full eval get_outputs "
-                         "(coarse+fine+reflect); train = BASELINE configs[2]: full training step (forward, loss, "
-                         "backward, gradient all-reduce, RAdam) with 64 coarse + 128 fine + reflect 64+64 samples")
+    ap.add_argument("--workload", default="train", choices=["train", "level", "get_outputs"],
+                    help="train = the BASELINE metric (default): full optimisation step; level = BASELINE configs[1], "
+                         "fused forward + composite of one sampling level (eval); get_outputs = full eval get_outputs")
     ap.add_argument("--mma", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
-                    help="matrix-core arithmetic of the eval field kernel: f32 = exact fp32 MFMA (default); bf16x6 = "
-                         "fp32 emulation by 3-way bf16 splits (fp32-equivalent results); bf16x3 = reduced precision")
+                    help="matrix-core arithmetic of the field kernels: f32 = exact fp32 MFMA (default); bf16x6 = fp32 "
+                         "emulation by 3-way bf16 splits (fp32-equivalent); bf16x3 / bf16 = reduced precision (eval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train-leg", action="store_true", help="skip the secondary training-step measurement")
-    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample (~10 s of CPU work)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (eval_level, configs[2])")
+    ap.add_argument("--cpu-rays", type=int, default=0, help="rays of the bounded CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """The oracle's single-level render on the host cores, bounded sample (cpu_rays x samples)."""
-    from oracle import cpu_ref
-
+def host_threads():
     # host cores this process may use: the GPU box gives a 1-GPU job a 16-core share of a 256-core host;
     # more threads than that only oversubscribes (measured: 256 threads = 18 rays/s)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(avail, int(os.environ.get("RSN_CPU_THREADS", "16")))))
+    return max(1, min(avail, int(os.environ.get("RSN_CPU_THREADS", "16"))))
+
+
+def cpu_baseline_level(args):
+    """The oracle's single-level eval render on the host cores, bounded sample."""
+    from oracle import cpu_ref
+
+    torch.set_num_threads(host_threads())
     fs = cpu_ref.FieldSpec(num_layers=args.layers, width=args.width)
     P = cpu_ref.init_params(fs, seed=0)
-    Rc = args.cpu_rays
+    Rc = args.cpu_rays or 1024
     o, d, pa = cpu_ref.synthetic_rays(Rc, seed=0)
     nears, fars = torch.full((Rc, 1), 2.0), torch.full((Rc, 1), 6.0)
     with torch.no_grad():
         cpu_ref.render_level(P, fs, o, d, pa, nears, fars, args.samples)  # warm-up
         times = []
-        t_end = time.time() + 20.0
-        while len(times) < 3 or (time.time() < t_end and len(times) < 10):
+        t_end = time.time() + 12.0
+        while len(times) < 3 or (time.time() < t_end and len(times) < 8):
             t0 = time.perf_counter()
             cpu_ref.render_level(P, fs, o, d, pa, nears, fars, args.samples)
             times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {
-        "value": Rc / med,
-        "unit": "rays/s",
-        "cores": torch.get_num_threads(),
-        "kind": "port",
-        "sample": f"{Rc} rays x {args.samples} samples, same field ({args.layers}x{args.width}) and level, "
-                  f"median of {len(times)} runs, oracle/cpu_ref.render_level (eager PyTorch fp32)",
-    }
+    return {"value": Rc / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{Rc} rays x {args.samples} samples, same field ({args.layers}x{args.width}) and level, "
+                      f"median of {len(times)} runs, oracle/cpu_ref.render_level (eager PyTorch fp32)"}
 
 
-def train_leg(pkg, args, dev, rank, world, dist, share):
-    """Secondary measurement of the default run: BASELINE configs[2]/[4], one full training step per rank (forward,
-    twelve loss terms, backward, ONE flat gradient all-reduce over RCCL when N > 1, fused RAdam), timed with the same
-    barrier + synchronize + max-over-ranks bracket.  Reported as `train_step` next to the headline; never `value`."""
-    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
-    from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, train_step
+def cpu_baseline_train(args, samples):
+    """The oracle's training step on the host cores: get_outputs(training) + the 8-term loss + autograd backward +
+    torch.optim.RAdam, bounded sample of the same workload (same field, same sample counts, fewer rays)."""
+    from oracle import cpu_ref
 
-    R = args.rays
-    torch.manual_seed(0)
-    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=64, num_importance_samples=128,
-                                            base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
-    model = cfg.setup(scene_box=None, num_train_data=1)
-    with torch.no_grad():
-        model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised
-    model.to(dev).train()
-    o, d, pa = synthetic_rays(R, seed=rank)
-    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.reshape(R, 1).to(dev),
-                       nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
-    params = model.get_param_groups()["fields"]
-    optimizer = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15, lr_final=1e-4, max_steps=50000)
-    reducer = FlatGradAllReduce(params) if world > 1 else None
-    batch = {"image": torch.rand(R, 3, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)}
-    steps, warmup, it = min(args.steps, 20), min(max(args.warmup, 1), 3), 100  # past the 50-step loss warm-up
-    for _ in range(warmup):
-        train_step(model, rb, batch, optimizer, reducer, it)
-        it += 1
+    torch.set_num_threads(host_threads())
+    fs = cpu_ref.FieldSpec(num_layers=args.layers, width=args.width)
+    ms = cpu_ref.ModelSpec(*samples)
+    P = {k: v.clone().requires_grad_(True) for k, v in cpu_ref.init_params(fs, seed=0, density_bias_shift=2.0).items()}
+    opt = torch.optim.RAdam([p for p in P.values()], lr=1e-3, eps=1e-15)
+    Rc = args.cpu_rays or 128
+    o, d, pa = cpu_ref.synthetic_rays(Rc, seed=0)
+    nears, fars = torch.full((Rc, 1), 2.0), torch.full((Rc, 1), 6.0)
+    image = torch.rand(Rc, 3, generator=torch.Generator().manual_seed(1234))
+    g = torch.Generator().manual_seed(5)
+    times, M = [], 0
+    t_end = time.time() + 25.0
+    while len(times) < 3 or (time.time() < t_end and len(times) < 6):
+        jit = {"coarse": torch.rand(Rc, samples[0] + 1, generator=g), "fine": torch.rand(Rc, samples[1] + 1, generator=g),
+               "reflect_coarse": torch.rand(Rc, samples[2] + 1, generator=g),
+               "reflect_fine": torch.rand(Rc, samples[3] + 1, generator=g)}
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        out = cpu_ref.get_outputs(P, fs, ms, o, d, pa, nears, fars, training=True, jitter=jit)
+        loss = sum(cpu_ref.loss_dict(out, image).values())
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        M = int(out["mask"].sum())
+    steady = sorted(times[1:])  # the first step pays allocator warm-up
+    med = steady[len(steady) // 2]
+    return {"value": Rc / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{Rc} rays x ({samples[0]} coarse + {samples[1]} fine + reflect {samples[2]} + {samples[3]} on "
+                      f"M={M} rays), same field ({args.layers}x{args.width}): oracle/cpu_ref.get_outputs(training) + "
+                      f"loss_dict + autograd backward + torch.optim.RAdam, median of {len(steady)} steps after 1 warm-up"}
+
+
+class Watchdog:
+    """Ends the process with rc 3 if the benchmark makes no progress for `limit` seconds (a rank lost in the gradient
+    all-reduce, a hung kernel): a stall must never read as rc 0."""
+
+    def __init__(self, rank, limit=240.0):
+        self.t = time.time()
+        self.rank, self.limit = rank, limit
+        self.done = threading.Event()
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self):
+        self.t = time.time()
+
+    def _run(self):
+        while not self.done.wait(timeout=5.0):
+            if time.time() - self.t > self.limit:
+                sys.stderr.write(json.dumps({"error": "bench.py stalled: no step finished for %.0f s on rank %d"
+                                                      % (self.limit, self.rank)}) + "\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+
+def timed_region(dist, share, dev, steps, fn):
+    """barrier + synchronize | K steps | synchronize + barrier; returns the max over ranks of the wall time."""
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = train_step(model, rb, batch, optimizer, reducer, it)
-        it += 1
+    for i in range(steps):
+        fn(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -133,13 +190,202 @@ def train_leg(pkg, args, dev, rank, world, dist, share):
         t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    with torch.no_grad():  # rays that take the reflect branch after the timed steps (training-mode forward, untimed)
-        mask_frac = float(model(rb)["mask"].float().mean())
-    return {"value": world * R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
-            "warmup": warmup, "n_gpus": world, "dtype": "f32", "loss": float(loss), "reflect_ray_fraction": mask_frac,
-            "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect (64 + 64) per rank, forward + "
-                        "12-term loss + backward + %s + fused RAdam" %
-                        (R, "one flat 618513-float gradient all-reduce (RCCL)" if world > 1 else "no collective (N=1)")}
+    return elapsed
+
+
+def newest_profile_traffic(kernel_name, rays, samples):
+    """HBM bytes per launch of `kernel_name` from the newest profiles/*_summary.json taken on this workload size."""
+    traffic = None
+    try:
+        for fn in sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_summary.json")):
+            with open(os.path.join(REPO, "profiles", fn)) as fh:
+                js = json.load(fh)
+            if js.get("kernel") == kernel_name and js.get("rays", 4096) == rays and js.get("samples", 128) == samples \
+                    and js.get("hbm_traffic_bytes_per_launch") is not None:
+                traffic = js["hbm_traffic_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+    return traffic
+
+
+TRAFFIC_NOTE = ("HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), separate rocprofv3 --pmc passes of "
+                "tools/profile_round.sh; newest profiles/*_summary.json taken on this kernel and workload size (null if none)")
+
+
+def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, dog, time_kernels=True):
+    """`steps` timed optimisation steps on this rank's rays; returns the train-step record (rank-0 relevant)."""
+    from reflect_sampling_nerf_amd import ops
+    from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, train_step
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
+
+    R = args.rays
+    torch.manual_seed(0)  # identical random-init weights on every rank (data-parallel replicas)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=samples[0], num_importance_samples=samples[1],
+                                            num_reflect_coarse_samples=samples[2],
+                                            num_reflect_importance_samples=samples[3],
+                                            base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised (SURVEY 8(d))
+    model.to(dev).train()
+    model.field.set_mma_mode(args.mma if args.mma in ("f32", "bf16x6") else "f32")
+    o, d, pa = synthetic_rays(R, seed=rank)  # each rank renders its own rays
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.reshape(R, 1).to(dev),
+                       nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
+    params = model.get_param_groups()["fields"]
+    optimizer = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15, lr_final=1e-4, max_steps=50000)  # config.py:50-53
+    reducer = FlatGradAllReduce(params) if world > 1 else None
+    batch = {"image": torch.rand(R, 3, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)}
+    state = {"it": 100, "M": 0, "loss": None}  # past the 50-step loss warm-up: all eight loss terms are live
+
+    def step(_i=None):
+        state["loss"] = train_step(model, rb, batch, optimizer, reducer, state["it"])
+        state["it"] += 1
+        state["M"] += int(getattr(model, "_last_num_reflected", 0))
+        dog.beat()
+
+    for _ in range(warmup):
+        step()
+    state["M"] = 0
+    timer = ops.KernelTimer() if time_kernels else None
+    ops.TIMER = timer
+    try:
+        elapsed = timed_region(dist, share, dev, steps, step)
+    finally:
+        ops.TIMER = None
+    macs = algorithmic_macs(args.layers, args.width)
+    rec = {"value": world * R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+           "warmup": warmup, "n_gpus": world, "loss": float(state["loss"]),
+           "reflect_ray_fraction": state["M"] / float(steps * R), "host_syncs_in_reducer":
+               (reducer.host_syncs if reducer is not None else 0)}
+    if timer is not None:
+        tot = timer.totals()
+        pts = lambda k: tot.get(k, {"work": {}})["work"].get("points", 0)  # noqa: E731
+        ms = lambda k: tot.get(k, {"ms": 0.0})["ms"]  # noqa: E731
+        calls = lambda k: tot.get(k, {"calls": 0})["calls"]  # noqa: E731
+        n_fwd = pts("field_forward_train_normals") + pts("field_forward_train")
+        n_bwd = pts("field_backward") + pts("field_backward_input")
+        flop = {
+            "forward": 2.0 * (macs["forward"] * n_fwd + macs["normals"] * pts("field_forward_train_normals")),
+            "backward": 2.0 * (macs["backward"] * pts("field_backward") + macs["backward_input"] * pts("field_backward_input")),
+            "wgrad": 2.0 * macs["wgrad"] * n_bwd,
+        }
+        kern = {}
+        for key, name, names in (
+                ("forward", "rsn_field_kernel<%d,true,%d>" % (args.width // 32, 1 if args.mma == "bf16x6" else 0),
+                 ("field_forward_train_normals", "field_forward_train")),
+                ("backward", "rsn_field_bwd_kernel<%d,%d>" % (args.width // 32, 1 if args.mma == "bf16x6" else 0),
+                 ("field_backward", "field_backward_input")),
+                ("wgrad", "rsn_wgrad_kernel", ("weight_grad",))):
+            t_ms = sum(ms(n) for n in names)
+            n_calls = sum(calls(n) for n in names)
+            tf = flop[key] / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+            kern[key] = {"kernel": name, "launches_per_step": n_calls / steps, "avg_launch_ms": t_ms / max(n_calls, 1),
+                         "ms_per_step": t_ms / steps, "algorithmic_flop_per_step": flop[key] / steps,
+                         "achieved_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS}
+        total_flop = sum(flop.values()) / steps
+        rec["kernels"] = kern
+        rec["algorithmic_flop_per_step"] = total_flop
+        rec["flop_formula"] = (
+            "per field point (MAC x 2): forward %d, analytic normals %d (primary levels), backward dX %d (%d where the "
+            "gradient reaches pixel_area: reflect levels, get_inf_color), weight gradients %d; points per step = "
+            "R*(Sc+Sf) primary + M*(Src+Srf+1) reflected with the MEASURED mean M = %.1f of R = %d" %
+            (macs["forward"], macs["normals"], macs["backward"], macs["backward_input"], macs["wgrad"],
+             state["M"] / float(steps), R))
+        rec["end_to_end_tflops"] = total_flop / (elapsed / steps) / 1e12
+        rec["end_to_end_frac_of_fp32_mfma_peak"] = rec["end_to_end_tflops"] / FP32_MFMA_PEAK_TFLOPS
+        rec["other_ms_per_step"] = elapsed / steps * 1e3 - sum(k["ms_per_step"] for k in kern.values())
+    return rec
+
+
+def run_level(pkg, args, dev, steps, warmup, dog):
+    """BASELINE configs[1] (secondary at N = 1): fused forward + composite of one sampling level, eval mode."""
+    from reflect_sampling_nerf_amd import ops
+    from reflect_sampling_nerf_amd._abi import RSN_SPACING_UNIFORM
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
+
+    R, S = args.rays, args.samples
+    torch.manual_seed(0)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S, num_importance_samples=S,
+                                            base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    model.to(dev).eval()
+    fld = model.field
+    fld.set_mma_mode(args.mma)
+    o, d, pa = synthetic_rays(R, seed=0)
+    o, d, pa = o.to(dev), d.to(dev), pa.reshape(R).to(dev)
+    nears, fars = torch.full((R,), 2.0, device=dev), torch.full((R,), 6.0, device=dev)
+    fld.packed_weights()
+    flags = ops.RSN_COMP_EVAL | ops.RSN_COMP_CLIP_RGB
+
+    def step(_i=None):
+        sb, eb = ops.sample_spaced(R, None, S, RSN_SPACING_UNIFORM, 1.0, nears, fars, None)
+        lv = fld.evaluate_frustums(o, d, pa, eb, full=True)
+        ops.composite(R, None, S, 1, flags, lv["sigma"], eb, lv["color"])
+        dog.beat()
+
+    for _ in range(warmup):
+        step()
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    try:
+        elapsed = timed_region(None, False, dev, steps, step)
+    finally:
+        ops.TIMER = None
+    t = timer.totals()["field_forward_eval"]
+    kms = t["ms"] / t["calls"]
+    macs = algorithmic_macs(args.layers, args.width)
+    flop = 2.0 * macs["forward"] * R * S
+    achieved = flop / (kms * 1e-3) / 1e12
+    mode_idx = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}[args.mma]
+    kname = ("rsn_field_bf16_kernel<%d>" % (args.width // 32)) if args.mma == "bf16" else \
+        "rsn_field_kernel<%d, false, %d>" % (args.width // 32, mode_idx)
+    # f32: algorithmic FLOP against the fp32-MFMA peak.  Split modes issue 6 (3) bf16 MFMA FLOP per algorithmic FLOP:
+    # priced as issued bf16 FLOP against the bf16 dense peak.
+    mult = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}[args.mma]
+    peak = FP32_MFMA_PEAK_TFLOPS if args.mma == "f32" else BF16_MFMA_PEAK_TFLOPS
+    return {
+        "workload": "%s: %d rays x %d samples, %d-layer %d-wide MLP, %s, fused forward + composite of one sampling level (eval)"
+                    % ("BASELINE configs[1]" if (R, S, args.mma) == (4096, 128, "f32") else
+                       "BASELINE configs[3]" if (R, S, args.mma) == (16384, 192, "bf16") else "custom size",
+                       R, S, args.layers, args.width,
+                       {"f32": "fp32", "bf16x6": "fp32 emulated on bf16 MFMA (6 products)", "bf16x3": "bf16x3 split",
+                        "bf16": "bf16 MFMA hidden GEMMs"}[args.mma]),
+        "value": R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+        "roofline": {"kernel": kname, "bound": "mfma", "achieved": achieved * mult, "algorithmic_tflops": achieved,
+                     "peak": peak, "unit": "TFLOP/s", "frac": achieved * mult / peak,
+                     "traffic": newest_profile_traffic(kname, R, S), "traffic_note": TRAFFIC_NOTE, "kernel_ms": kms,
+                     "algorithmic_flop_per_launch": flop},
+    }
+
+
+def run_get_outputs(pkg, args, dev, steps, warmup, dog):
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
+
+    R, S = args.rays, args.samples
+    torch.manual_seed(0)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S, num_importance_samples=S,
+                                            base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 2.0
+    model.to(dev).eval()
+    model.field.set_mma_mode(args.mma)
+    o, d, pa = synthetic_rays(R, seed=0)
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.reshape(R, 1).to(dev),
+                       nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
+    state = {}
+
+    def step(_i=None):
+        state["out"] = model(rb)
+        dog.beat()
+
+    for _ in range(warmup):
+        step()
+    elapsed = timed_region(None, False, dev, steps, step)
+    return {"workload": "full eval get_outputs: %d rays x (%d coarse + %d fine + reflect 64 + 64), %dx%d field, M/R=%.2f"
+                        % (R, S, S, args.layers, args.width, float(state["out"]["mask"].float().mean())),
+            "value": R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps}
 
 
 def main():
@@ -147,10 +393,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     # rehearsal on a 1-GPU box: RSN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
     # ranks on one device); the real run is one rank per GPU over RCCL ("nccl" backend on ROCm).
@@ -159,224 +404,105 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    dog = Watchdog(rank)
 
     import reflect_sampling_nerf_amd as pkg
-    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
-    from reflect_sampling_nerf_amd import ops
-    from reflect_sampling_nerf_amd._abi import RSN_SPACING_UNIFORM
 
     pkg.load_library()
-    torch.manual_seed(0)  # identical random-init weights on every rank (data parallel replicas)
     R, S = args.rays, args.samples
-    if args.workload == "train":
-        cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=64, num_importance_samples=128,
-                                                base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
-    else:
-        cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S, num_importance_samples=S,
-                                                base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width)
-    model = cfg.setup(scene_box=None, num_train_data=1)
-    if args.workload in ("get_outputs", "train"):
-        with torch.no_grad():
-            model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised
-    model.to(dev).eval()
-    if args.workload == "train":
-        model.train()
-    fld = model.field
-    fld.set_mma_mode(args.mma)
-    o, d, pa = synthetic_rays(R, seed=rank)  # each rank renders its own rays
-    o, d, pa = o.to(dev), d.to(dev), pa.reshape(R).to(dev)
-    nears = torch.full((R,), 2.0, device=dev)
-    fars = torch.full((R,), 6.0, device=dev)
-    rb = pkg.RayBundle(origins=o, directions=d, pixel_area=pa[:, None], nears=nears[:, None], fars=fars[:, None])
-    fld.packed_weights()
-    flags = ops.RSN_COMP_EVAL | ops.RSN_COMP_CLIP_RGB
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    state = {}
-
-    if args.workload == "train":
-        from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce, train_step
-
-        params = model.get_param_groups()["fields"]
-        optimizer = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15, lr_final=1e-4, max_steps=50000)  # config.py:50-53
-        reducer = FlatGradAllReduce(params) if world > 1 else None
-        g = torch.Generator().manual_seed(1234 + rank)
-        batch = {"image": torch.rand(R, 3, generator=g).to(dev)}
-        state["it"] = 100  # past the 50-step loss warm-up: all twelve loss terms are live
-
-    def step(i=None):
-        if args.workload == "train":
-            state["loss"] = train_step(model, rb, batch, optimizer, reducer, state["it"])
-            state["it"] += 1
-            return
-        if args.workload == "get_outputs":
-            state["out"] = model(rb)
-            return
-        sb, eb = ops.sample_spaced(R, None, S, RSN_SPACING_UNIFORM, 1.0, nears, fars, None)
-        if i is not None:
-            ev[i][0].record()
-        lv = fld.evaluate_frustums(o, d, pa, eb, full=True)
-        if i is not None:
-            ev[i][1].record()
-        state["out"] = ops.composite(R, None, S, 1, flags, lv["sigma"], eb, lv["color"])
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if args.workload == "level" and args.mma == "f32" and world == 1:
-        # informational: the same workload with the fp32-emulating split-bf16 matrix-core mode (results agree with
-        # the exact-fp32 path to ~2e-7, tests/test_gpu_parity.py); `value` above stays the exact-fp32 number
-        alt = {}
-        for mode in ("bf16x6",):
-            fld.set_mma_mode(mode)
-            for _ in range(args.warmup):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            alt[mode] = {"value": R * args.steps / dt, "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3,
-                         "note": "fp32 emulation: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate"}
-        fld.set_mma_mode("f32")
-        state["alt"] = alt
-    if args.workload != "level":
-        with torch.no_grad():
-            model.eval()
-            state["mask_frac"] = float(model(rb)["mask"].float().mean())
+    samples = (args.coarse or S, S, 64, 64)
     line = None
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * R * args.steps / elapsed
-        line = {
-            "metric": "rays/sec (train step) at 4096 rays x 128 samples, 1/2/4/8 MI355X; PSNR vs ref",
-            "value": value,
-            "unit": "rays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x6": "f32 (emulated: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate)",
-                      "bf16x3": "bf16x3 (2-way bf16 split, f32 accumulate; reduced precision)",
-                      "bf16": "bf16 (bf16 MFMA operands, f32 accumulate; BASELINE configs[3])"}[args.mma],
-            "data": "synthetic",
-            "config": {
-                "workload": ("%s: %d rays x %d samples, %d-layer %d-wide MLP, %s, fused forward + composite of one "
-                             "sampling level (eval)" %
-                             ("BASELINE configs[1]" if (R, S, args.mma) == (4096, 128, "f32") else
-                              "BASELINE configs[3]" if (R, S, args.mma) == (16384, 192, "bf16") else "custom size",
-                              R, S, args.layers, args.width,
-                              {"f32": "fp32", "bf16x6": "fp32 emulated on bf16 MFMA (6 products)",
-                               "bf16x3": "bf16x3 split", "bf16": "bf16 MFMA hidden GEMMs"}[args.mma]))
-                if args.workload == "level" else
-                ("full %s: %d rays x (%d coarse + %d fine + reflect %d + %d), %dx%d field, M/R=%.2f" %
-                 ("training step (forward+loss+backward+grad all-reduce+RAdam, BASELINE configs[2])"
-                  if args.workload == "train" else "eval get_outputs",
-                  R, cfg.num_coarse_samples, cfg.num_importance_samples, cfg.num_reflect_coarse_samples,
-                  cfg.num_reflect_importance_samples, args.layers, args.width,
-                  float(state.get("mask_frac", float("nan"))))),
-                "rays_per_gpu": R,
-                "samples_per_ray": S,
-                "parallelism": ("dp%d (independent ray batches, no data-path collective)" % world) if args.workload != "train"
-                else ("dp%d (one flat %d-float gradient all-reduce per step over RCCL)" % (world, 618513)),
-                "weights": "random-init (nn.Linear default), seed 0",
-            },
-        }
-        if args.workload == "level":
-            kms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-            flop = FLOP_PER_SAMPLE * R * S if (args.layers, args.width) == (8, 256) else None
-            if flop is not None:
-                achieved = flop / (kms * 1e-3) / 1e12
-                traffic = None  # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/)
-                kname = "rsn_field_kernel<8, false, %d>" % {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}[args.mma]
-                try:  # newest summary (by name) that was taken on this kernel instantiation and this workload size
-                    for fn in sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_summary.json")):
-                        with open(os.path.join(REPO, "profiles", fn)) as fh:
-                            js = json.load(fh)
-                        if js.get("kernel") == kname and js.get("rays", 4096) == R and js.get("samples", 128) == S \
-                                and js.get("hbm_traffic_bytes_per_launch") is not None:
-                            traffic = js["hbm_traffic_bytes_per_launch"]
-                except (OSError, ValueError):
-                    pass
-                # f32: algorithmic FLOP against the fp32-MFMA peak.  Split modes issue 6 (3) bf16 MFMA FLOP per
-                # algorithmic FLOP: priced as issued bf16 FLOP against the bf16 dense peak.
-                mult = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}[args.mma]
-                peak = FP32_MFMA_PEAK_TFLOPS if args.mma == "f32" else BF16_MFMA_PEAK_TFLOPS
-                line["roofline"] = {
-                    "kernel": "rsn_field_kernel<8,false,%d>" % {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}[args.mma],
-                    "bound": "mfma",
-                    "achieved": achieved * mult,
-                    "algorithmic_tflops": achieved,
-                    "peak": peak,
-                    "unit": "TFLOP/s",
-                    "frac": achieved * mult / peak,
-                    "traffic": traffic,
-                    "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), separate --pmc "
-                                    "passes of tools/profile_round.sh; newest profiles/*_summary.json taken on this "
-                                    "kernel instantiation and workload size (null if none)",
-                    "kernel_ms": kms,
-                    "algorithmic_flop_per_launch": flop,
-                }
-        if "alt" in state:
-            line["alt_mma_modes"] = state["alt"]
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args)
-    if args.workload == "level" and args.mma == "f32" and not args.no_train_leg:
-        # Secondary leg, every rank.  It must never cost the headline line: a watchdog prints the line without it
-        # and ends the process if the leg does not come back (a rank lost inside the gradient all-reduce).
-        import threading
-
-        finished = threading.Event()
-
-        def watchdog():
-            if finished.wait(timeout=240.0):
-                return
+    try:
+        if args.workload == "train":
+            rec = run_train(pkg, args, dev, rank, world, dist, share, samples, args.steps, args.warmup, dog)
             if rank == 0:
-                line["train_step"] = {"error": "training leg did not finish within 240 s; headline unaffected"}
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            res = train_leg(pkg, args, dev, rank, world, dist, share)
-        except Exception as exc:
-            res = {"error": "%s: %s" % (type(exc).__name__, exc)}
-            if world > 1:  # the other ranks may be waiting in a collective: leave it to their watchdogs
-                finished.set()
-                if rank == 0:
-                    line["train_step"] = res
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
-        finished.set()
-        if rank == 0:
-            line["train_step"] = res
+                fwd = rec["kernels"]["forward"]
+                line = {
+                    "metric": "rays/sec (train step) at 4096 rays x 128 samples, 1/2/4/8 MI355X; PSNR vs ref",
+                    "value": rec["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f32" if args.mma == "f32" else "f32 (emulated: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate)",
+                    "data": "synthetic",
+                    "config": {
+                        "workload": "training step per rank: %d rays x (%d coarse + %d fine + reflect %d + %d on the M "
+                                    "reflected rays), %d-layer %d-wide field: forward (stratified jitter, analytic normals) "
+                                    "+ 8-term loss + backward + %s + fused RAdam; M/R = %.2f"
+                                    % (R, samples[0], samples[1], samples[2], samples[3], args.layers, args.width,
+                                       ("ONE flat 618513-float gradient all-reduce (%s, %d ranks)" % (backend, world))
+                                       if world > 1 else "no collective (N=1)", rec["reflect_ray_fraction"]),
+                        "rays_per_gpu": R, "samples_per_ray": S, "global_rays_per_step": world * R,
+                        "parallelism": "dp%d" % world,
+                        "collective": None if world == 1 else "all-reduce(sum)/N of one flat fp32 gradient buffer per step",
+                        "rccl_ranks": dist.get_world_size() if (dist is not None and backend == "nccl") else 0,
+                        "backend": backend,
+                        "weights": "random-init (nn.Linear default), seed 0, density bias +2",
+                    },
+                    "roofline": {
+                        "kernel": fwd["kernel"] + " (training forward: saved activations + in-kernel analytic normals)",
+                        "bound": "mfma", "achieved": fwd["achieved_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": fwd["frac_of_fp32_mfma_peak"],
+                        "traffic": newest_profile_traffic(fwd["kernel"], R, S), "traffic_note": TRAFFIC_NOTE,
+                        "avg_launch_ms": fwd["avg_launch_ms"], "launches_per_step": fwd["launches_per_step"],
+                        "algorithmic_flop_per_step": fwd["algorithmic_flop_per_step"],
+                        "share_of_step_time": fwd["ms_per_step"] / rec["ms_per_step"],
+                    },
+                    "train_step": {k: rec[k] for k in ("algorithmic_flop_per_step", "flop_formula", "kernels",
+                                                       "end_to_end_tflops", "end_to_end_frac_of_fp32_mfma_peak",
+                                                       "other_ms_per_step", "loss", "reflect_ray_fraction",
+                                                       "host_syncs_in_reducer")},
+                }
+            if world == 1 and not args.no_secondary and args.mma == "f32":
+                # secondary legs (untimed for the headline): configs[1] eval level and the configs[2] training shape
+                lv = run_level(pkg, args, dev, args.steps, args.warmup, dog)
+                c2 = run_train(pkg, args, dev, rank, world, None, share, (64, 128, 64, 64), min(args.steps, 10),
+                               min(max(args.warmup, 1), 3), dog, time_kernels=False)
+                line["eval_level"] = lv
+                line["train_step_configs2"] = {
+                    "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect 64 + 64, forward + backward "
+                                "(+ loss + RAdam)" % R,
+                    **{k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "reflect_ray_fraction")}}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline_train(args, samples)
+                dog.beat()
+                if "eval_level" in line:
+                    line["eval_level"]["cpu_baseline"] = cpu_baseline_level(args)
+        else:
+            assert world == 1, "--workload level / get_outputs are single-GPU measurements"
+            rec = run_level(pkg, args, dev, args.steps, args.warmup, dog) if args.workload == "level" else \
+                run_get_outputs(pkg, args, dev, args.steps, args.warmup, dog)
+            line = {
+                "metric": "rays/sec (%s) at %d rays x %d samples, 1 MI355X" %
+                          ("eval forward + composite of one level" if args.workload == "level" else "eval get_outputs", R, S),
+                "value": rec["value"], "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": {"f32": "f32", "bf16x6": "f32 (emulated: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate)",
+                          "bf16x3": "bf16x3 (2-way bf16 split, f32 accumulate; reduced precision)",
+                          "bf16": "bf16 (bf16 MFMA operands, f32 accumulate; BASELINE configs[3])"}[args.mma],
+                "data": "synthetic",
+                "config": {"workload": rec["workload"], "rays_per_gpu": R, "samples_per_ray": S, "parallelism": "dp1",
+                           "weights": "random-init (nn.Linear default), seed 0"},
+            }
+            if "roofline" in rec:
+                line["roofline"] = rec["roofline"]
+            if args.workload == "level" and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline_level(args)
+    except BaseException:
+        sys.stderr.write(json.dumps({"error": "bench.py failed on rank %d" % rank, "traceback": traceback.format_exc()}) + "\n")
+        sys.stderr.flush()
+        if world > 1:  # the other ranks may sit in a collective: do not wait for them in destroy_process_group
+            os._exit(4)
+        sys.exit(4)
+    dog.done.set()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -447,13 +447,28 @@ def field_level(P, fs: FieldSpec, origins, directions, pixel_area, eucl_bins, tr
 
 def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Tensor, directions: Tensor,
                 pixel_area: Tensor, nears: Tensor, fars: Tensor, training: bool = False,
-                jitter: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+                jitter: Optional[Dict[str, Tensor]] = None, bins: Optional[Dict[str, Tensor]] = None,
+                record_bins: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """Restatement of ReflectSamplingNeRFModel.get_outputs (model.py:142-344).
 
     jitter (training only): {"coarse": [R,Sc+1], "fine": [R,Sf+1], "reflect_coarse": [M,Src+1],
     "reflect_fine": [M,Srf+1]} uniform [0,1) draws that replace the samplers' torch.rand calls.
+    bins (tests): {"<level>_spacing": [n,S+1], "<level>_euclid": [n,S+1]} for level in coarse / fine / reflect_coarse /
+    reflect_fine replaces that level's sampler output (the samplers' outputs are constants of the graph: PDFSampler
+    detaches, model.py:182,317), so that two pipelines can be compared on identical sample positions.
+    record_bins: a dict that receives every level's bins under the same keys.
     """
     jitter = jitter or {}
+    bins = bins or {}
+
+    def level_bins(name, computed):
+        sb, eb = computed
+        if name + "_euclid" in bins:
+            sb, eb = bins[name + "_spacing"], bins[name + "_euclid"]
+        if record_bins is not None:
+            record_bins[name + "_spacing"], record_bins[name + "_euclid"] = sb.detach().clone(), eb.detach().clone()
+        return sb, eb
+
     white = torch.ones(3)
     jit = (lambda k: jitter[k]) if training else (lambda k: None)
 
@@ -463,7 +478,7 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
         return t[mask] if (t is not None and t.shape[0] == mask.shape[0] and t.shape[0] != int(mask.sum())) else t
 
     # A. coarse primary (model.py:148-177)
-    sbins_c, ebins_c = spaced_bins("uniform", 1.0, nears, fars, ms.num_coarse, jit("coarse"))
+    sbins_c, ebins_c = level_bins("coarse", spaced_bins("uniform", 1.0, nears, fars, ms.num_coarse, jit("coarse")))
     lc = field_level(P, fs, origins, directions, pixel_area, ebins_c, training, want_normals=True)
     w_c = weights_from_density(lc["sigma"], lc["t0"], lc["t1"])
     acc_c = torch.sum(w_c, dim=-2)
@@ -471,8 +486,8 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     rgb_c = torch.clip(composite_rgb(lc["color"], w_c, white, training), 0.0, 1.0)
 
     # B. fine primary (model.py:182-211)
-    sbins_f, ebins_f = pdf_bins("uniform", 1.0, nears, fars, w_c, sbins_c, ms.num_fine, jit("fine"),
-                                ms.histogram_padding)
+    sbins_f, ebins_f = level_bins("fine", pdf_bins("uniform", 1.0, nears, fars, w_c, sbins_c, ms.num_fine, jit("fine"),
+                                                   ms.histogram_padding))
     lf = field_level(P, fs, origins, directions, pixel_area, ebins_f, training, want_normals=True)
     w_f = weights_from_density(lf["sigma"], lf["t0"], lf["t1"])
     acc_f = torch.sum(w_f, dim=-2)
@@ -523,8 +538,8 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     background = inf_color(P, fs, d2, sqradius)
 
     # F. reflect coarse (model.py:292-313)
-    sb_rc, eb_rc = spaced_bins("reciprocal", ms.reflect_tan, near2, far2, ms.num_reflect_coarse,
-                               jit_reflect("reflect_coarse", mask))
+    sb_rc, eb_rc = level_bins("reflect_coarse", spaced_bins("reciprocal", ms.reflect_tan, near2, far2,
+                                                            ms.num_reflect_coarse, jit_reflect("reflect_coarse", mask)))
     lrc = field_level(P, fs, o2, d2, pa2, eb_rc, training, want_normals=False)
     w_rc = weights_from_density(lrc["sigma"], lrc["t0"], lrc["t1"]).detach()
     comp_rc = composite_rgb(lrc["color"], w_rc, background, training)
@@ -533,8 +548,9 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     out["mid_reflect_coarse"] = rc
 
     # G. reflect fine (model.py:317-342)
-    sb_rf, eb_rf = pdf_bins("reciprocal", ms.reflect_tan, near2, far2, w_rc, sb_rc, ms.num_reflect_fine,
-                            jit_reflect("reflect_fine", mask), ms.histogram_padding)
+    sb_rf, eb_rf = level_bins("reflect_fine", pdf_bins("reciprocal", ms.reflect_tan, near2, far2, w_rc, sb_rc,
+                                                       ms.num_reflect_fine, jit_reflect("reflect_fine", mask),
+                                                       ms.histogram_padding))
     lrf = field_level(P, fs, o2, d2, pa2, eb_rf, training, want_normals=False)
     w_rf = weights_from_density(lrf["sigma"], lrf["t0"], lrf["t1"]).detach()
     comp_rf = composite_rgb(lrf["color"], w_rf, background, training)

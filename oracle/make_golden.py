@@ -67,6 +67,48 @@ class RandLog:
         torch.rand = self._orig
 
 
+class BinLog:
+    """Forward hooks on the model's four samplers: records the (spacing, euclidean) bin edges [n, S+1] each one returns
+    (reference call sites model.py:148,182,292,317), so that another pipeline can be run on identical sample positions."""
+
+    NAMES = {"sampler_uniform": "coarse", "sampler_pdf": "fine", "sampler_reciprocal": "reflect_coarse",
+             "sampler_reflect_pdf": "reflect_fine"}
+
+    def __init__(self, model):
+        self.bins = {}
+        self.handles = []
+        for attr, name in self.NAMES.items():
+            self.handles.append(getattr(model, attr).register_forward_hook(self._hook(name)))
+
+    def _hook(self, name):
+        def hook(_module, _inputs, rs):
+            n, S = rs.frustums.starts.shape[0], rs.frustums.starts.shape[1]
+            edges = lambda a, b: torch.cat([a[..., 0], b[..., -1:, 0]], dim=-1).expand(n, S + 1).detach().clone()  # noqa: E731
+            self.bins[name + "_euclid"] = edges(rs.frustums.starts, rs.frustums.ends)
+            self.bins[name + "_spacing"] = edges(rs.spacing_starts, rs.spacing_ends)
+        return hook
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+def save_params(arrays, model, param_file):
+    """Parameters go into the case file, or -- for the 2.5 MB networks several cases share -- once into
+    tests/golden/<param_file>.npz (the case's meta names it)."""
+    P = {k: v.detach().numpy().astype(np.float32) for k, v in model.field.state_dict().items()}
+    if param_file is None:
+        for k, v in P.items():
+            arrays["param/" + k] = v
+        return
+    path = os.path.join(OUT_DIR, param_file + ".npz")
+    if os.path.exists(path):
+        old = np.load(path)
+        assert all(np.array_equal(old[k], v) for k, v in P.items()), f"{param_file}: cases do not share parameters"
+    else:
+        np.savez_compressed(path, **P)
+
+
 def build_model(samples, layers, width, seed, density_bias_shift):
     torch.manual_seed(seed)
     cfg = ReflectSamplingNeRFModelConfig(
@@ -90,9 +132,10 @@ def build_model(samples, layers, width, seed, density_bias_shift):
     return model
 
 
-def run_case(name, R, samples, layers, width, training, seed, density_bias_shift, near=2.0, far=6.0):
+def run_case(name, R, samples, layers, width, training, seed, density_bias_shift, near=2.0, far=6.0, param_file=None,
+             ray_seed=None):
     model = build_model(samples, layers, width, seed, density_bias_shift)
-    o, d, pa = synthetic_rays(R, seed=seed + 100)
+    o, d, pa = synthetic_rays(R, seed=(seed if ray_seed is None else ray_seed) + 100)
     nears = torch.full((R, 1), near)
     fars = torch.full((R, 1), far)
     bundle = RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=pa.clone(), nears=nears.clone(),
@@ -100,15 +143,18 @@ def run_case(name, R, samples, layers, width, training, seed, density_bias_shift
     model.train(training)
     torch.manual_seed(seed + 7)
     sink = io.StringIO()
+    binlog = BinLog(model)
     with RandLog() as log, contextlib.redirect_stdout(sink):  # the reference prints debug lines
         if training:
             out = model.get_outputs(bundle)
         else:
             with torch.no_grad():
                 out = model.get_outputs(bundle)
+    binlog.close()
     arrays = {}
-    for k, v in model.field.state_dict().items():
-        arrays["param/" + k] = v.detach().numpy().astype(np.float32)
+    save_params(arrays, model, param_file)
+    for k, v in binlog.bins.items():
+        arrays["bins/" + k] = v.numpy()
     for k, v in [("origins", o), ("directions", d), ("pixel_area", pa), ("nears", nears), ("fars", fars)]:
         arrays["in/" + k] = v.numpy()
     for k, v in out.items():
@@ -121,7 +167,7 @@ def run_case(name, R, samples, layers, width, training, seed, density_bias_shift
             arrays["jitter/" + n] = t.numpy()
     meta = dict(name=name, R=R, samples=list(samples), layers=layers, width=width, training=training, seed=seed,
                 density_bias_shift=density_bias_shift, near=near, far=far,
-                M=int(out["mask"].sum()), keys=sorted(out.keys()),
+                M=int(out["mask"].sum()), keys=sorted(out.keys()), param_file=param_file,
                 generator="oracle/make_golden.py over /root/reference + oracle/ns_shim",
                 torch=torch.__version__)
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -130,12 +176,13 @@ def run_case(name, R, samples, layers, width, training, seed, density_bias_shift
     print(f"{name}: R={R} M={meta['M']} keys={len(out)} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
-def run_train_step_case(name, R, samples, layers, width, seed, density_bias_shift, near=2.0, far=6.0):
+def run_train_step_case(name, R, samples, layers, width, seed, density_bias_shift, near=2.0, far=6.0, param_file=None,
+                        ray_seed=None):
     """One whole training step of the reference: get_outputs (train mode, logged jitter) -> get_loss_dict
     (model.py:346-430, post-warm-up coefficients of the config) -> backward.  Stores the outputs, the eight scaled loss
     terms and the gradient of their sum w.r.t. every Field parameter."""
     model = build_model(samples, layers, width, seed, density_bias_shift)
-    o, d, pa = synthetic_rays(R, seed=seed + 100)
+    o, d, pa = synthetic_rays(R, seed=(seed if ray_seed is None else ray_seed) + 100)
     nears, fars = torch.full((R, 1), near), torch.full((R, 1), far)
     bundle = RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=pa.clone(), nears=nears.clone(),
                        fars=fars.clone())
@@ -143,14 +190,17 @@ def run_train_step_case(name, R, samples, layers, width, seed, density_bias_shif
     model.train(True)
     torch.manual_seed(seed + 7)
     sink = io.StringIO()
+    binlog = BinLog(model)
     with RandLog() as log, contextlib.redirect_stdout(sink):
         out = model.get_outputs(bundle)
         loss_dict = model.get_loss_dict(out, {"image": image})
         total = sum(loss_dict.values())
         total.backward()
+    binlog.close()
     arrays = {}
-    for k, v in model.field.state_dict().items():
-        arrays["param/" + k] = v.detach().numpy().astype(np.float32)
+    save_params(arrays, model, param_file)
+    for k, v in binlog.bins.items():
+        arrays["bins/" + k] = v.numpy()
     n_grad = 0
     for k, p in model.field.named_parameters():
         if p.grad is not None:
@@ -169,6 +219,7 @@ def run_train_step_case(name, R, samples, layers, width, seed, density_bias_shif
     meta = dict(name=name, R=R, samples=list(samples), layers=layers, width=width, training=True, seed=seed,
                 density_bias_shift=density_bias_shift, near=near, far=far, M=int(out["mask"].sum()),
                 keys=sorted(out.keys()), loss_coefficients={k: float(v) for k, v in model.config.loss_coefficients.items()},
+                param_file=param_file,
                 generator="oracle/make_golden.py over /root/reference + oracle/ns_shim (get_outputs + get_loss_dict + backward)",
                 torch=torch.__version__)
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -261,6 +312,20 @@ def main():
     # one whole training step (forward + the reference's own get_loss_dict + backward) at a width the HIP path runs
     run_train_step_case("trainstep_l8_w64", R=32, samples=(16, 16, 8, 8), layers=8, width=64, seed=6,
                         density_bias_shift=2.0)
+    # ---- shapes the HIP kernels run (widths 64 / 128 / 256), compared with the reference's outputs DIRECTLY on the GPU
+    # the BASELINE network (8 x 256, field.py:40-41 defaults): eval and one whole training step on the same parameters
+    run_case("eval_l8_w256", R=16, samples=(16, 16, 8, 8), layers=8, width=256, training=False, seed=10,
+             density_bias_shift=2.0, param_file="params_l8_w256_seed10")
+    run_train_step_case("trainstep_l8_w256", R=16, samples=(16, 16, 8, 8), layers=8, width=256, seed=10,
+                        density_bias_shift=2.0, param_file="params_l8_w256_seed10", ray_seed=20)
+    # 4-layer 128-wide trunk (BASELINE configs[0] network): eval with ragged sample counts, and a training step
+    run_case("eval_l4_w128", R=24, samples=(24, 12, 10, 6), layers=4, width=128, training=False, seed=11,
+             density_bias_shift=1.5, param_file="params_l4_w128_seed11")
+    run_train_step_case("trainstep_l4_w128", R=24, samples=(16, 16, 8, 8), layers=4, width=128, seed=11,
+                        density_bias_shift=1.5, param_file="params_l4_w128_seed11", ray_seed=21)
+    # the no-mask early-out (model.py:259-260) at a width the kernels accept
+    run_case("eval_l6_w64_nomask", R=16, samples=(8, 8, 8, 8), layers=6, width=64, training=False, seed=4,
+             density_bias_shift=-12.0)
     run_units()
 
 

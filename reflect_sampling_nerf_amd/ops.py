@@ -19,6 +19,44 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Measurement hook (bench.py, tools/): while one is installed as `ops.TIMER`, the dominant kernels' launches are
+    bracketed by HIP events on the stream they are launched on (torch's current stream), tagged with a name and the
+    work of the launch; `totals()` reads the events after a synchronize.  Not installed -> zero overhead."""
+
+    def __init__(self):
+        self.spans = []
+
+    def add(self, name, start, end, work):
+        self.spans.append((name, start, end, work))
+
+    def totals(self):
+        out = {}
+        for name, s, e, work in self.spans:
+            t = out.setdefault(name, {"calls": 0, "ms": 0.0, "work": {}})
+            t["calls"] += 1
+            t["ms"] += s.elapsed_time(e)
+            for k, v in (work or {}).items():
+                t["work"][k] = t["work"].get(k, 0) + v
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def timed(name: str, work: Optional[Dict], fn):
+    """Run `fn()` (one C-ABI launch); under an installed KernelTimer, between two events on the launch stream."""
+    t = TIMER
+    if t is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    t.add(name, s, e, work)
+    return r
+
+
 def _f32c(t: Tensor) -> Tensor:
     if t.dtype != torch.float32 or not t.is_contiguous():
         t = t.contiguous().float()

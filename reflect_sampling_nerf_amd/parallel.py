@@ -3,13 +3,24 @@
 One process per GPU, each rendering its own ray batch; the only exchange is the gradient average.  The Field
 has 618,513 fp32 parameters (2.47 MB), so the collective is latency bound: ONE flat buffer, ONE all-reduce
 (RCCL over xGMI when the backend is "nccl"), then a scale by 1/world -- exactly DDP's averaging, including its
-`find_unused_parameters=True` behaviour: a parameter that received no gradient on this rank (field_output_low
-always; the reflect-only path when no ray of this rank is reflected) contributes zeros, and a parameter unused on
-EVERY rank keeps `grad is None`.
+`find_unused_parameters=True` behaviour: a parameter that received no gradient on this rank contributes zeros, and
+a parameter unused on EVERY rank keeps `grad is None`.
+
+Steady state has no host work beyond Python bookkeeping: no host->device copy, no device->host read, no
+synchronisation.  The all-reduce runs on the reducer's own stream (pack on the compute stream -> event ->
+all-reduce + 1/world scale on the side stream -> event -> the compute stream waits before it unpacks), so anything
+the caller enqueues that does not touch the gradients overlaps with the collective.
+
+  * Which parameters never receive a gradient on any rank (field_output_low: built by field.py:67, never evaluated)
+    is decided ONCE, on the first call, by one extra flag all-reduce; they are dropped from the flat buffer.
+  * The per-step "was used" flags of the live parameters travel in the tail of the same flat buffer.  They are kept on
+    the device (one cached tensor per distinct None-pattern) and are only read back on a step where THIS rank lacks a
+    gradient some other rank may have produced -- which the reflect-sampling model never does (train_graph.py hands
+    every live parameter a gradient even when no ray of the rank is reflected, like the reference: model.py:240-241).
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -18,20 +29,45 @@ import torch.distributed as dist
 class FlatGradAllReduce:
     """Averages `.grad` of `params` across the process group with a single all-reduce of one flat buffer."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, side_stream: bool = True):
+        self.all_params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.params: Optional[List[torch.nn.Parameter]] = None  # live parameters, fixed by the first call
         self.group = process_group
+        self.use_side_stream = side_stream
+        self._flat: Optional[torch.Tensor] = None
+        self._flags: Dict[Tuple[bool, ...], torch.Tensor] = {}
+        self._stream = None
+        self.host_syncs = 0  # device->host reads issued by the reducer (tests assert it stays at the one-time 1)
+
+    # ------------------------------------------------------------------------------------------------ one-time set-up
+    def _decide_live(self) -> None:
+        """First call only: parameters without a gradient on EVERY rank are statically unused -> never reduced."""
+        p0 = self.all_params[0]
+        have = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.all_params], dtype=torch.float32)
+        gloo = dist.get_backend(self.group) == "gloo"
+        t = have if gloo else have.to(p0.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        used = t.cpu()
+        self.host_syncs += 1
+        self.params = [p for p, u in zip(self.all_params, used.tolist()) if u > 0.0]
         self.sizes = [p.numel() for p in self.params]
         self.total = sum(self.sizes)
-        self._flat: Optional[torch.Tensor] = None
+        n = self.total + len(self.params)  # gradients + one "was used" flag per live parameter
+        self._flat = torch.zeros(n, device=p0.device, dtype=p0.dtype)
+        self._views = [v.view_as(p) for v, p in zip(self._flat[: self.total].split(self.sizes), self.params)]
+        if self.use_side_stream and p0.is_cuda:
+            self._stream = torch.cuda.Stream(device=p0.device)
+            self._packed_ev = torch.cuda.Event()
+            self._reduced_ev = torch.cuda.Event()
 
-    def _buffer(self, device, dtype):
-        n = self.total + len(self.params)  # gradients + one "was used" flag per parameter
-        if self._flat is None or self._flat.device != device or self._flat.dtype != dtype:
-            self._flat = torch.zeros(n, device=device, dtype=dtype)
-            self._views = [v.view_as(p) for v, p in zip(self._flat[: self.total].split(self.sizes), self.params)]
-        return self._flat
+    def _flag_tensor(self, have: Tuple[bool, ...]) -> torch.Tensor:
+        t = self._flags.get(have)
+        if t is None:  # one host->device copy per distinct pattern, ever
+            t = torch.tensor([1.0 if h else 0.0 for h in have], dtype=self._flat.dtype).to(self._flat.device)
+            self._flags[have] = t
+        return t
 
+    # ------------------------------------------------------------------------------------------------ every step
     @torch.no_grad()
     def __call__(self) -> None:
         if not dist.is_available() or not dist.is_initialized():
@@ -39,29 +75,45 @@ class FlatGradAllReduce:
         world = dist.get_world_size(self.group)
         if world == 1:
             return
-        p0 = self.params[0]
-        flat = self._buffer(p0.device, p0.dtype)
-        have = [p.grad is not None for p in self.params]
-        # pack: one multi-tensor copy for the gradients that exist, zeros elsewhere, the flags in one transfer
-        if not all(have):
+        if self.params is None:
+            self._decide_live()
+        flat = self._flat
+        have = tuple(p.grad is not None for p in self.params)
+        complete = all(have)
+        # pack (compute stream): one multi-tensor copy for the gradients that exist, zeros elsewhere, flags device-side
+        if not complete:
             flat[: self.total].zero_()
         src = [p.grad for p, h in zip(self.params, have) if h]
+        dst = self._views if complete else [v for v, h in zip(self._views, have) if h]
         if src:
-            torch._foreach_copy_([v for v, h in zip(self._views, have) if h], src)
-        flat[self.total:].copy_(torch.tensor([1.0 if h else 0.0 for h in have], dtype=flat.dtype), non_blocking=True)
-        if dist.get_backend(self.group) == "gloo" and flat.is_cuda:  # CPU rehearsal backend: stage through host
+            torch._foreach_copy_(dst, src)
+        flat[self.total:].copy_(self._flag_tensor(have))
+        gloo_cuda = dist.get_backend(self.group) == "gloo" and flat.is_cuda
+        if gloo_cuda:  # CPU rehearsal backend (two ranks sharing one GPU): stage through the host
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat.copy_(host)
+            flat[: self.total].mul_(1.0 / world)
+        elif self._stream is not None:
+            cur = torch.cuda.current_stream(flat.device)
+            self._packed_ev.record(cur)
+            with torch.cuda.stream(self._stream):
+                self._stream.wait_event(self._packed_ev)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)  # RCCL; its work is ordered on this stream
+                flat[: self.total].mul_(1.0 / world)
+                self._reduced_ev.record(self._stream)
+            cur.wait_event(self._reduced_ev)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat[: self.total].mul_(1.0 / world)
-        # unpack: gradients that exist locally are overwritten in one multi-tensor copy; only when this rank lacks
-        # some does it need the summed flags (one host read) to tell "zeros" from "unused everywhere -> stays None"
+            flat[: self.total].mul_(1.0 / world)
+        # unpack: gradients that exist locally are overwritten in one multi-tensor copy
         if src:
-            torch._foreach_copy_(src, [v for v, h in zip(self._views, have) if h])
-        if not all(have):
+            torch._foreach_copy_(src, dst)
+        if not complete:
+            # this rank lacks a gradient: the summed flags tell "zeros from me, data from others" apart from "unused
+            # on every rank this step -> stays None" (DDP, find_unused_parameters=True).  The only host read.
             used = flat[self.total:].cpu()
+            self.host_syncs += 1
             for i, (p, h) in enumerate(zip(self.params, have)):
                 if not h and float(used[i]) > 0.0:
                     p.grad = self._views[i].clone()

@@ -195,9 +195,10 @@ class ReflectSamplingNeRFNerfField(Field):
                           "roughness": f(R, S)})
         fo = ops.field_outputs_struct(level)
         desc = self.field_desc()
-        check(lib.rsn_field_forward_frustum(C.byref(desc), ptr(self.packed_weights()), R, ptr(n_dev), S, ptr(origins),
-                                            ptr(directions), ptr(pixel_area), ptr(euclid_bins), C.byref(fo),
-                                            ops._stream()))
+        pk = self.packed_weights()
+        ops.timed("field_forward_eval" if full else "field_forward_eval_color", {"points": R * S}, lambda: check(
+            lib.rsn_field_forward_frustum(C.byref(desc), ptr(pk), R, ptr(n_dev), S, ptr(origins), ptr(directions),
+                                          ptr(pixel_area), ptr(euclid_bins), C.byref(fo), ops._stream())))
         return level
 
     def evaluate_frustums_train(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid_bins: Tensor,
@@ -220,9 +221,11 @@ class ReflectSamplingNeRFNerfField(Field):
         for k, v in saved.items():
             setattr(fs, k, ptr(v))
         desc = self.field_desc()
-        check(lib.rsn_field_forward_frustum_train(C.byref(desc), ptr(self.packed_weights()), R, ptr(n_dev), S,
-                                                  ptr(origins), ptr(directions), ptr(pixel_area), ptr(euclid_bins),
-                                                  C.byref(fo), C.byref(fs), ops._stream()))
+        pk = self.packed_weights()
+        ops.timed("field_forward_train_normals" if want_normals else "field_forward_train", {"points": N}, lambda: check(
+            lib.rsn_field_forward_frustum_train(C.byref(desc), ptr(pk), R, ptr(n_dev), S, ptr(origins), ptr(directions),
+                                                ptr(pixel_area), ptr(euclid_bins), C.byref(fo), C.byref(fs),
+                                                ops._stream())))
         level["saved"] = saved
         if want_normals:
             level["normals"] = saved["normals"]

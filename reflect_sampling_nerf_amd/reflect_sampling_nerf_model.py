@@ -105,9 +105,11 @@ class ReflectSamplingNeRFModel(Model):
             return self._get_outputs_train(ray_bundle)
         return self._get_outputs_eval(ray_bundle)
 
-    def _get_outputs_train(self, ray_bundle, jitter: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+    def _get_outputs_train(self, ray_bundle, jitter: Optional[Dict[str, Tensor]] = None,
+                           bins: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
         """Training mode: one autograd node (train_graph.GetOutputsTrain) over the HIP forward/backward kernels.
-        `jitter` optionally injects the samplers' uniform draws (tests share them with the oracle)."""
+        `jitter` optionally injects the samplers' uniform draws and `bins` whole sampler outputs
+        ({"fine_spacing", "fine_euclid", ...}); tests share them with the oracle / the reference's logged values."""
         from .train_graph import DIFF_KEYS, GetOutputsTrain
 
         R = ray_bundle.origins.shape[0]
@@ -116,7 +118,7 @@ class ReflectSamplingNeRFModel(Model):
         pa = ops._f32c(ray_bundle.pixel_area.reshape(R))
         nears = ops._f32c(ray_bundle.nears.reshape(R))
         fars = ops._f32c(ray_bundle.fars.reshape(R))
-        outs = GetOutputsTrain.apply(self, o, d, pa, nears, fars, jitter, *self.field.parameters())
+        outs = GetOutputsTrain.apply(self, o, d, pa, nears, fars, jitter, bins, *self.field.parameters())
         outputs = dict(zip(DIFF_KEYS, outs))
         aux = self._train_aux
         self._train_aux = None

@@ -157,8 +157,9 @@ def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Opti
     dys = (C.c_void_p * ns)(*[dy.data_ptr() for dy, _ in segs])
     xs = (C.c_void_p * ns)(*[x.data_ptr() for _, x in segs])
     dwp = C.c_void_p(dw.data_ptr() + 4 * dw_col0)
-    check(lib.rsn_weight_grad_multi(ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp, dw.stride(0),
-                                    ptr(db), ops._stream()))
+    ops.timed("weight_grad", {"point_out_in": sum(dy.shape[0] for dy, _ in segs) * n_out * k_in},
+              lambda: check(lib.rsn_weight_grad_multi(ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp,
+                                                      dw.stride(0), ptr(db), ops._stream())))
 
 
 def _weight_grads(field, levels, acc: _GradAcc):
@@ -199,9 +200,11 @@ def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], ne
     fo = ops.field_outputs_struct(level)
     fs = _saved_struct(level["saved"])
     desc = field.field_desc()
-    check(lib.rsn_field_backward_frustum(C.byref(desc), ptr(field.packed_weights()), n, None, S, ptr(o), ptr(d),
-                                         ptr(pa), ptr(eb), C.byref(fo), C.byref(fs), C.byref(gi), C.byref(gst),
-                                         1 if need_input else 0, ops._stream()))
+    pk = field.packed_weights()
+    ops.timed("field_backward_input" if need_input else "field_backward", {"points": n * S}, lambda: check(
+        lib.rsn_field_backward_frustum(C.byref(desc), ptr(pk), n, None, S, ptr(o), ptr(d), ptr(pa), ptr(eb),
+                                       C.byref(fo), C.byref(fs), C.byref(gi), C.byref(gst), 1 if need_input else 0,
+                                       ops._stream())))
     return gout
 
 
@@ -218,11 +221,14 @@ DIFF_KEYS = ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflec
 
 
 class GetOutputsTrain(torch.autograd.Function):
-    """inputs: (model, ray tensors, jitter dict or None, *field parameters) -> tuple of DIFF_KEYS tensors.
-    The non-differentiable outputs are left on `model._train_aux` by forward."""
+    """inputs: (model, ray tensors, jitter dict or None, bins dict or None, *field parameters) -> tuple of DIFF_KEYS
+    tensors.  The non-differentiable outputs are left on `model._train_aux` by forward.
+    jitter: the samplers' uniform draws; bins: {"<level>_spacing", "<level>_euclid"} [n,S+1] replacing the sampler
+    output of a level (the samplers' outputs are constants of the graph: PDFSampler detaches, model.py:182,317) --
+    tests use both to put this pipeline and the reference / the oracle on identical sample positions."""
 
     @staticmethod
-    def forward(ctx, model, o, d, pa, nears, fars, jitter, *params):
+    def forward(ctx, model, o, d, pa, nears, fars, jitter, bins, *params):
         cfg, fld = model.config, model.field
         R, dev = o.shape[0], o.device
         Sc, Sf = cfg.num_coarse_samples, cfg.num_importance_samples
@@ -230,21 +236,32 @@ class GetOutputsTrain(torch.autograd.Function):
         CLIP = ops.RSN_COMP_CLIP_RGB
         uni, rec = model.sampler_uniform.spec, model.sampler_reciprocal.spec
         jitter = jitter or {}
+        bins = bins or {}
 
         def jit(name, n, S):
             t = jitter.get(name)
             return ops._f32c(t.to(dev)) if t is not None else torch.rand(n, S + 1, device=dev)
 
+        def level_bins(name, n, S, sample):
+            """the level's (spacing, euclidean) bins: injected ones if given, else the sampler launch `sample()`"""
+            if name + "_euclid" in bins:
+                sb, eb = (ops._f32c(bins[name + k].to(dev).reshape(n, S + 1)) for k in ("_spacing", "_euclid"))
+                return sb, eb
+            return sample()
+
         # A. coarse, B. fine (+ per-ray surface attributes)
-        sb_c, eb_c = ops.sample_spaced(R, None, Sc, uni.spacing, uni.tan, nears, fars, jit("coarse", R, Sc))
+        sb_c, eb_c = level_bins("coarse", R, Sc, lambda: ops.sample_spaced(R, None, Sc, uni.spacing, uni.tan, nears, fars,
+                                                                           jit("coarse", R, Sc)))
         lc = fld.evaluate_frustums_train(o, d, pa, eb_c, want_normals=True)
         cc = ops.composite(R, None, Sc, 1, CLIP, lc["sigma"], eb_c, lc["color"])
-        sb_f, eb_f = ops.sample_pdf(R, None, Sc, Sf, uni.spacing, uni.tan, model.sampler_pdf.histogram_padding, nears,
-                                    fars, cc["weights"], sb_c, jit("fine", R, Sf))
+        sb_f, eb_f = level_bins("fine", R, Sf, lambda: ops.sample_pdf(
+            R, None, Sc, Sf, uni.spacing, uni.tan, model.sampler_pdf.histogram_padding, nears, fars, cc["weights"], sb_c,
+            jit("fine", R, Sf)))
         lf = fld.evaluate_frustums_train(o, d, pa, eb_f, want_normals=True)
         cf = ops.composite(R, None, Sf, 1, CLIP, lf["sigma"], eb_f, lf["color"], level=lf, surface=True)
         rs = ops.reflect_setup(o, d, cf["accumulation"], cf["depth"], cf["normals"], cf["roughness"], float(model.far))
         M = int(rs["n_masked"].item())  # training: one sync here sizes the reflect buffers exactly
+        model._last_num_reflected = M
 
         aux = {
             "accumulation_coarse": cc["accumulation"].unsqueeze(-1), "accumulation_fine": cf["accumulation"].unsqueeze(-1),
@@ -268,16 +285,18 @@ class GetOutputsTrain(torch.autograd.Function):
             bg = f(M, 3)
             desc = fld.field_desc()
             fs = _saved_struct(inf_saved)
-            check(lib.rsn_field_forward_inf_train(C.byref(desc), ptr(fld.packed_weights()), M, None, ptr(d2), ptr(sq),
-                                                  ptr(bg), C.byref(fs), ops._stream()))
-            sb_rc, eb_rc = ops.sample_spaced(M, None, Src, rec.spacing, rec.tan, near2, far2,
-                                             jit("reflect_coarse", M, Src))
+            pk = fld.packed_weights()
+            ops.timed("field_forward_train", {"points": M}, lambda: check(
+                lib.rsn_field_forward_inf_train(C.byref(desc), ptr(pk), M, None, ptr(d2), ptr(sq), ptr(bg), C.byref(fs),
+                                                ops._stream())))
+            sb_rc, eb_rc = level_bins("reflect_coarse", M, Src, lambda: ops.sample_spaced(
+                M, None, Src, rec.spacing, rec.tan, near2, far2, jit("reflect_coarse", M, Src)))
             lrc = fld.evaluate_frustums_train(o2, d2, pa2, eb_rc, want_normals=False)
             crc = ops.composite(M, None, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
             ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
-            sb_rf, eb_rf = ops.sample_pdf(M, None, Src, Srf, rec.spacing, rec.tan,
-                                          model.sampler_reflect_pdf.histogram_padding, near2, far2, crc["weights"],
-                                          sb_rc, jit("reflect_fine", M, Srf))
+            sb_rf, eb_rf = level_bins("reflect_fine", M, Srf, lambda: ops.sample_pdf(
+                M, None, Src, Srf, rec.spacing, rec.tan, model.sampler_reflect_pdf.histogram_padding, near2, far2,
+                crc["weights"], sb_rc, jit("reflect_fine", M, Srf)))
             lrf = fld.evaluate_frustums_train(o2, d2, pa2, eb_rf, want_normals=False)
             crf = ops.composite(M, None, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
             ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
@@ -330,8 +349,10 @@ class GetOutputsTrain(torch.autograd.Function):
             gout, gst = _alloc_gout(fld, M, dev, True)
             desc = fld.field_desc()
             fs = _saved_struct(st["inf_saved"])
-            check(lib.rsn_field_backward_inf(C.byref(desc), ptr(fld.packed_weights()), M, None, ptr(st["rays2"][1]),
-                                             ptr(st["sq"]), C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream()))
+            pk = fld.packed_weights()
+            ops.timed("field_backward_input", {"points": M}, lambda: check(
+                lib.rsn_field_backward_inf(C.byref(desc), ptr(pk), M, None, ptr(st["rays2"][1]), ptr(st["sq"]),
+                                           C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream())))
             pending.append((st["inf_saved"], gout, False))
             g_r = torch.empty(R, device=dev)
             check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
@@ -364,4 +385,4 @@ class GetOutputsTrain(torch.autograd.Function):
         final = acc.finish()
         grads = [final.get(name) for name, _ in fld.named_parameters()]  # field_output_low: unused -> None
         ctx.st = None
-        return (None,) * 7 + tuple(grads)
+        return (None,) * 8 + tuple(grads)

@@ -17,6 +17,9 @@ def load_golden(name):
             continue
         grp, key = k.split("/", 1)
         groups.setdefault(grp, {})[key] = torch.from_numpy(z[k])
+    if meta.get("param_file"):  # parameters shared by several cases live in their own file
+        pz = np.load(os.path.join(GOLDEN, meta["param_file"] + ".npz"), allow_pickle=False)
+        groups["param"] = {k: torch.from_numpy(pz[k]) for k in pz.files}
     return meta, groups
 
 

@@ -8,7 +8,10 @@ import torch
 from oracle import cpu_ref
 from tests.helpers import field_spec_from_meta, load_golden, max_abs, model_spec_from_meta
 
-CASES = ["eval_l8_w32", "train_l8_w32", "eval_l4_w32", "eval_l6_w32_nomask", "eval_l8_w64_near0"]
+CASES = ["eval_l8_w32", "train_l8_w32", "eval_l4_w32", "eval_l6_w32_nomask", "eval_l8_w64_near0",
+         # shapes the HIP kernels run (tests/test_gpu_parity.py compares the HIP path with the same files directly)
+         "eval_l8_w256", "eval_l4_w128", "eval_l6_w64_nomask"]
+TRAIN_STEP_CASES = ["trainstep_l8_w64", "trainstep_l8_w256", "trainstep_l4_w128"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -17,9 +20,14 @@ def test_get_outputs_matches_reference(name):
     fs, ms = field_spec_from_meta(meta), model_spec_from_meta(meta)
     i = g["in"]
     torch.manual_seed(0)
+    rec = {}
     out = cpu_ref.get_outputs(g["param"], fs, ms, i["origins"], i["directions"], i["pixel_area"], i["nears"],
-                              i["fars"], training=meta["training"], jitter=g.get("jitter"))
+                              i["fars"], training=meta["training"], jitter=g.get("jitter"), record_bins=rec)
     ref = g["out"]
+    # the sampler outputs the reference logged (forward hooks on its four samplers): same bin edges
+    assert sorted(rec) == sorted(g["bins"])
+    for k, v in g["bins"].items():
+        assert max_abs(rec[k], v) <= (2e-6 if k.endswith("spacing") or "reflect" not in k else 2e-5), k
     assert sorted(out.keys()) == sorted(ref.keys()) == meta["keys"]
     assert torch.equal(out["mask"].to(torch.uint8), ref["mask"])
     assert int(out["mask"].sum()) == meta["M"]
@@ -34,6 +42,8 @@ def test_get_outputs_matches_reference(name):
 
 def test_nomask_case_takes_early_out():
     meta, g = load_golden("eval_l6_w32_nomask")
+    assert meta["M"] == 0 and "depth_reflect_fine" not in g["out"]
+    meta, g = load_golden("eval_l6_w64_nomask")
     assert meta["M"] == 0 and "depth_reflect_fine" not in g["out"]
 
 
@@ -88,16 +98,18 @@ def test_param_count_matches_reference_default():
     assert sum(v.numel() for v in P.values()) == 618513
 
 
-def test_train_step_matches_reference():
+@pytest.mark.parametrize("name", TRAIN_STEP_CASES)
+@pytest.mark.parametrize("inject_bins", [False, True])
+def test_train_step_matches_reference(name, inject_bins):
     """One whole training step of the REFERENCE (get_outputs in train mode -> its own get_loss_dict -> backward,
-    tests/golden/trainstep_l8_w64.npz): the oracle's outputs, its restated loss terms and autograd's gradients
-    through the oracle must reproduce the reference's."""
-    meta, g = load_golden("trainstep_l8_w64")
+    tests/golden/trainstep_*.npz): the oracle's outputs, its restated loss terms and autograd's gradients through the
+    oracle must reproduce the reference's -- free-running from the logged jitter, and on the reference's logged bins."""
+    meta, g = load_golden(name)
     fs, ms = field_spec_from_meta(meta), model_spec_from_meta(meta)
     i = g["in"]
     P = {k: v.clone().requires_grad_(True) for k, v in g["param"].items()}
     out = cpu_ref.get_outputs(P, fs, ms, i["origins"], i["directions"], i["pixel_area"], i["nears"], i["fars"],
-                              training=True, jitter=g["jitter"])
+                              training=True, jitter=g["jitter"], bins=g["bins"] if inject_bins else None)
     assert torch.equal(out["mask"].to(torch.uint8), g["out"]["mask"]) and int(out["mask"].sum()) == meta["M"] > 0
     for k, v in g["out"].items():
         if k != "mask":

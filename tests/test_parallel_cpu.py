@@ -30,7 +30,8 @@ def _worker(rank, world, port, out):
         params[2].grad = torch.randn(2, 2, generator=g)
     # parameter 3 is unused everywhere (field_output_low)
     local = [None if p.grad is None else p.grad.clone() for p in params]
-    FlatGradAllReduce(params)()
+    reducer = FlatGradAllReduce(params)
+    reducer()
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
     ok = True
@@ -41,6 +42,19 @@ def _worker(rank, world, port, out):
         else:
             mean = sum(torch.zeros_like(p) if x is None else x for x in gs) / world
             ok &= p.grad is not None and torch.allclose(p.grad, mean, atol=1e-7)
+    # the statically unused parameter was dropped from the flat buffer by the one-time decision
+    ok &= len(reducer.params) == 3 and reducer.total == 15 + 7 + 4
+    # steady state (every live parameter has a gradient on every rank, the reflect-sampling model's case): further
+    # steps average correctly and issue NO device->host read -- the one-time decision stays the only one on rank 0
+    syncs_before = reducer.host_syncs
+    for step in range(3):
+        for i in range(3):
+            params[i].grad = torch.full_like(params[i], float(rank + 1 + step))
+        reducer()
+        for i in range(3):
+            ok &= torch.allclose(params[i].grad, torch.full_like(params[i], 1.5 + step))
+        ok &= params[3].grad is None
+    ok &= reducer.host_syncs == syncs_before
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
