@@ -415,12 +415,18 @@ def pdf_bins(kind: str, tan: float, nears: Tensor, fars: Tensor, w: Tensor, spac
 # --------------------------------------------------------------------------------------
 
 
-def field_level(P, fs: FieldSpec, origins, directions, pixel_area, eucl_bins, training: bool, want_normals: bool):
+def field_level(P, fs: FieldSpec, origins, directions, pixel_area, eucl_bins, training: bool, want_normals: bool,
+                mean_override: Optional[Tensor] = None):
     """Stages A/B/F/G of SURVEY §3.3 up to the per-sample colour.  Returns a dict of per-sample tensors.
-    want_normals => analytic normals via autograd (training only; field.py:125-127,146-147)."""
+    want_normals => analytic normals via autograd (training only; field.py:125-127,146-147).
+    mean_override (tests): contracted Gaussian means [n,S,3] used instead of the computed ones (which carry no
+    gradient: origins, directions and bins are constants of the graph) -- puts two pipelines on bit-identical
+    positions; the covariance (which does carry gradient on the reflect levels) is still computed here."""
     t0, t1 = eucl_bins[..., :-1], eucl_bins[..., 1:]
     mean, cov = gaussian_blob(origins, directions, pixel_area, t0, t1)
     mean, cov = contract(mean, cov)
+    if mean_override is not None:
+        mean = mean_override.detach().reshape(mean.shape)
     if want_normals and training:
         mean = mean.detach().requires_grad_(True)  # field.py:126 (cov was computed before: constants)
     enc = ipe(fs, mean, torch.diagonal(cov, dim1=-2, dim2=-1))
@@ -448,7 +454,8 @@ def field_level(P, fs: FieldSpec, origins, directions, pixel_area, eucl_bins, tr
 def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Tensor, directions: Tensor,
                 pixel_area: Tensor, nears: Tensor, fars: Tensor, training: bool = False,
                 jitter: Optional[Dict[str, Tensor]] = None, bins: Optional[Dict[str, Tensor]] = None,
-                record_bins: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+                record_bins: Optional[Dict[str, Tensor]] = None,
+                means: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """Restatement of ReflectSamplingNeRFModel.get_outputs (model.py:142-344).
 
     jitter (training only): {"coarse": [R,Sc+1], "fine": [R,Sf+1], "reflect_coarse": [M,Src+1],
@@ -457,9 +464,12 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     reflect_fine replaces that level's sampler output (the samplers' outputs are constants of the graph: PDFSampler
     detaches, model.py:182,317), so that two pipelines can be compared on identical sample positions.
     record_bins: a dict that receives every level's bins under the same keys.
+    means (tests): {"coarse" | "fine" | "reflect_coarse" | "reflect_fine": [n,S,3]} contracted sample means to
+    evaluate the field at (field_level's mean_override).
     """
     jitter = jitter or {}
     bins = bins or {}
+    means = means or {}
 
     def level_bins(name, computed):
         sb, eb = computed
@@ -479,7 +489,8 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
 
     # A. coarse primary (model.py:148-177)
     sbins_c, ebins_c = level_bins("coarse", spaced_bins("uniform", 1.0, nears, fars, ms.num_coarse, jit("coarse")))
-    lc = field_level(P, fs, origins, directions, pixel_area, ebins_c, training, want_normals=True)
+    lc = field_level(P, fs, origins, directions, pixel_area, ebins_c, training, want_normals=True,
+                     mean_override=means.get("coarse"))
     w_c = weights_from_density(lc["sigma"], lc["t0"], lc["t1"])
     acc_c = torch.sum(w_c, dim=-2)
     depth_c = median_depth(w_c, lc["t0"], lc["t1"])
@@ -488,7 +499,8 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     # B. fine primary (model.py:182-211)
     sbins_f, ebins_f = level_bins("fine", pdf_bins("uniform", 1.0, nears, fars, w_c, sbins_c, ms.num_fine, jit("fine"),
                                                    ms.histogram_padding))
-    lf = field_level(P, fs, origins, directions, pixel_area, ebins_f, training, want_normals=True)
+    lf = field_level(P, fs, origins, directions, pixel_area, ebins_f, training, want_normals=True,
+                     mean_override=means.get("fine"))
     w_f = weights_from_density(lf["sigma"], lf["t0"], lf["t1"])
     acc_f = torch.sum(w_f, dim=-2)
     depth_f = median_depth(w_f, lf["t0"], lf["t1"])
@@ -540,7 +552,7 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     # F. reflect coarse (model.py:292-313)
     sb_rc, eb_rc = level_bins("reflect_coarse", spaced_bins("reciprocal", ms.reflect_tan, near2, far2,
                                                             ms.num_reflect_coarse, jit_reflect("reflect_coarse", mask)))
-    lrc = field_level(P, fs, o2, d2, pa2, eb_rc, training, want_normals=False)
+    lrc = field_level(P, fs, o2, d2, pa2, eb_rc, training, want_normals=False, mean_override=means.get("reflect_coarse"))
     w_rc = weights_from_density(lrc["sigma"], lrc["t0"], lrc["t1"]).detach()
     comp_rc = composite_rgb(lrc["color"], w_rc, background, training)
     rc = out["mid_reflect_coarse"].clone()
@@ -551,7 +563,7 @@ def get_outputs(P: Dict[str, Tensor], fs: FieldSpec, ms: ModelSpec, origins: Ten
     sb_rf, eb_rf = level_bins("reflect_fine", pdf_bins("reciprocal", ms.reflect_tan, near2, far2, w_rc, sb_rc,
                                                        ms.num_reflect_fine, jit_reflect("reflect_fine", mask),
                                                        ms.histogram_padding))
-    lrf = field_level(P, fs, o2, d2, pa2, eb_rf, training, want_normals=False)
+    lrf = field_level(P, fs, o2, d2, pa2, eb_rf, training, want_normals=False, mean_override=means.get("reflect_fine"))
     w_rf = weights_from_density(lrf["sigma"], lrf["t0"], lrf["t1"]).detach()
     comp_rf = composite_rgb(lrf["color"], w_rf, background, training)
     rf = out["mid_reflect_fine"].clone()

@@ -303,6 +303,11 @@ class GetOutputsTrain(torch.autograd.Function):
             aux["depth_reflect_fine"] = crf["depth"].unsqueeze(-1)
             st.update(rays2=(o2, d2, pa2), sq=sq, bg=bg, inf_saved=inf_saved, eb_rc=eb_rc, eb_rf=eb_rf, lrc=lrc, lrf=lrf,
                       crc=crc, crf=crf)
+        if getattr(model, "_keep_train_state", False):  # test hook: the sample positions this pass evaluated
+            st.update(sb_c=sb_c, sb_f=sb_f)
+            if M > 0:
+                st.update(sb_rc=sb_rc, sb_rf=sb_rf)
+            model._train_state = st
         ctx.st = st
         ctx.model = model
         ctx.n_params = len(params)
