@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 9
+#define RSN_ABI_VERSION 10
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -96,6 +96,7 @@ typedef struct rsn_field_outputs {
   float* tint;         /* [N,3]  get_tint                             field.py:182-186 */
   float* roughness;    /* [N]    sigmoid(roughness head)              field.py:150-155 (default act) */
   float* raw_density;  /* [N]    density head before bias/softplus    field.py:133-135 */
+  float* raw_roughness;/* [N]    roughness head before its activation field.py:150-155 (caller-chosen act) */
 } rsn_field_outputs;
 
 /* Activations the training-mode forward keeps for the backward pass (all row-major fp32, N = n_rays*n_samples

@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 9
+RSN_ABI_VERSION = 10
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -48,7 +48,8 @@ class FieldParams(C.Structure):
 
 class FieldOutputs(C.Structure):
     _fields_ = [(n, _fp) for n in
-                ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density")]
+                ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density",
+                 "raw_roughness")]
 
 
 class FieldSaved(C.Structure):

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           }
           if (a.out.n_dot_d) a.out.n_dot_d[pc] = vd[0] * nx + vd[1] * ny + vd[2] * nz;
           if (a.out.roughness) a.out.roughness[pc] = sigmoid_f(r4);
+          if (a.out.raw_roughness) a.out.raw_roughness[pc] = r4;
         } else {
           if (a.out.diff) {
             a.out.diff[pc * 3 + 0] = dcol[0]; a.out.diff[pc * 3 + 1] = dcol[1]; a.out.diff[pc * 3 + 2] = dcol[2];

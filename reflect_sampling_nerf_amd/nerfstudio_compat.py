@@ -146,9 +146,13 @@ except ImportError:
             image_shape = camera_ray_bundle.origins.shape[:-1]
             n = int(torch.tensor(image_shape).prod())
             lists: Dict[str, list] = {}
+            n_chunks = 0
             for i in range(0, n, chunk):
                 rb = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, min(i + chunk, n))
+                n_chunks += 1
                 for k, v in self.forward(rb).items():
                     if isinstance(v, Tensor) and v.shape[:1] == (len(rb),):
                         lists.setdefault(k, []).append(v)
-            return {k: torch.cat(v).view(*image_shape, *v[0].shape[1:]) for k, v in lists.items()}
+            # per-ray outputs only: a key that is not [rays, ...] in every chunk (depth_reflect_fine is [M,1]) is no image
+            return {k: torch.cat(v).view(*image_shape, *v[0].shape[1:]) for k, v in lists.items()
+                    if len(v) == n_chunks and k != "depth_reflect_fine"}

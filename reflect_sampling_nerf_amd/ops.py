@@ -151,7 +151,8 @@ def reflect_combine(n_max: int, n_masked: Tensor, ray_index: Tensor, diff: Tenso
 
 def field_outputs_struct(level: Dict[str, Tensor]) -> FieldOutputs:
     fo = FieldOutputs()
-    for name in ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density"):
+    for name in ("sigma", "color", "pred_normals", "n_dot_d", "diff", "tint", "roughness", "raw_density",
+                 "raw_roughness"):
         setattr(fo, name, ptr(level.get(name)))
     return fo
 

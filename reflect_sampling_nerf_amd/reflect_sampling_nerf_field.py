@@ -324,7 +324,7 @@ class ReflectSamplingNeRFNerfField(Field):
         lv = {"color": f(N, 3)}
         if not mid_only:
             lv.update({"pred_normals": f(N, 3), "diff": f(N, 3), "tint": f(N, 3), "roughness": f(N),
-                       "raw_density": f(N), "sigma": f(N)})
+                       "raw_density": f(N), "sigma": f(N), "raw_roughness": f(N)})
         vd = None if view_dirs is None else ops._f32c(view_dirs.expand(*shp, 3).reshape(-1, 3))
         rg = None if roughness is None else ops._f32c(roughness.expand(*shp, 1).reshape(-1))
         fo = ops.field_outputs_struct(lv)
@@ -344,11 +344,10 @@ class ReflectSamplingNeRFNerfField(Field):
 
     def get_roughness(self, embedding: Tensor, activation: Optional[nn.Module] = None) -> Tensor:
         """field.py:150-155: activation(roughness head); default Sigmoid."""
-        sig = self._heads(embedding)["roughness"]
+        heads = self._heads(embedding)
         if activation is None or isinstance(activation, nn.Sigmoid):
-            return sig
-        raw = torch.logit(sig)  # the kernel returns sigmoid(raw); other activations are applied to raw
-        return activation(raw)
+            return heads["roughness"]
+        return activation(heads["raw_roughness"])  # the caller's activation on the raw head output (any magnitude)
 
     def get_diff(self, embedding: Tensor) -> Tensor:
         """field.py:176-180."""

@@ -612,6 +612,14 @@ def test_granular_field_api(dev):
     assert max_abs(fld.get_tint(emb_dev).cpu(), tint_ref) <= TOL
     assert max_abs(fld.get_roughness(emb_dev).cpu(), torch.sigmoid(rr)) <= TOL
     assert max_abs(fld.get_roughness(emb_dev, torch.nn.Softplus()).cpu(), torch.nn.functional.softplus(rr)) <= TOL
+    # large head outputs (|raw| >> 17, where sigmoid saturates in fp32): the activation sees the RAW head value
+    big = emb_ref * 400.0
+    with torch.no_grad():
+        rr_big = cpu_ref.head(P, "field_output_roughness", big)
+    assert float(rr_big.abs().max()) > 30.0
+    got = fld.get_roughness(big.to(dev), torch.nn.Softplus()).cpu()
+    want = torch.nn.functional.softplus(rr_big)
+    assert bool(torch.isfinite(got).all()) and float(((got - want).abs() / (1.0 + want.abs())).max()) <= 1e-5
     assert max_abs(fld.get_mid(dirs.to(dev), rough.to(dev), emb_dev).cpu(), mid_ref) <= TOL
     assert max_abs(fld.get_low(emb_dev).cpu(), low_ref) <= TOL
     refl, ndd = fld.get_reflection(dirs.to(dev), pn_ref.to(dev))
@@ -621,26 +629,65 @@ def test_granular_field_api(dev):
 
 
 def test_camera_ray_bundle_chunked_eval(dev):
-    """Model.get_outputs_for_camera_ray_bundle: chunks of eval_num_rays_per_chunk rays, reshaped to the image."""
+    """SURVEY 8(f) row 4, the eval-image path (config.py:41, model.py:432-482): a 12 x 21 image rendered by
+    Model.get_outputs_for_camera_ray_bundle in chunks of eval_num_rays_per_chunk = 100 rays (252 = 100 + 100 + 52: the
+    chunk size does not divide H*W) against the CPU oracle run on all 252 rays at once, then
+    get_image_metrics_and_images against an independent plain-torch CPU computation on the same outputs."""
+    import math
+
     torch.manual_seed(3)
+    samples = (16, 16, 8, 8)
     cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=16, num_importance_samples=16,
                                             num_reflect_coarse_samples=8, num_reflect_importance_samples=8,
                                             base_mlp_num_layers=4, base_mlp_layer_width=64, eval_num_rays_per_chunk=100)
-    model = cfg.setup(scene_box=None, num_train_data=1).to(dev).eval()
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 1.5
+    P = {k: v.detach().clone() for k, v in model.field.state_dict().items()}
+    model.to(dev).eval()
     H, Wd = 12, 21
-    o, d, pa = cpu_ref.synthetic_rays(H * Wd, seed=9)
+    n = H * Wd
+    assert n % cfg.eval_num_rays_per_chunk != 0
+    o, d, pa = cpu_ref.synthetic_rays(n, seed=9)
     rb = pkg.RayBundle(origins=o.reshape(H, Wd, 3).to(dev), directions=d.reshape(H, Wd, 3).to(dev),
-                       pixel_area=pa.reshape(H, Wd, 1).to(dev))
+                       pixel_area=pa.reshape(H, Wd, 1).to(dev))  # no nears/fars: the collider fills them
     img = model.get_outputs_for_camera_ray_bundle(rb)
-    assert img["mid_rgb_fine"].shape == (H, Wd, 3) and img["accumulation_fine"].shape == (H, Wd, 1)
-    flat = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev))
-    whole = model(flat)
-    assert max_abs(img["mid_rgb_fine"].reshape(-1, 3), whole["mid_rgb_fine"]) <= 1e-6
-    # the eval-image hook (the reference's own raises KeyError at model.py:438)
-    metrics, images = model.get_image_metrics_and_images(img, {"image": torch.rand(H, Wd, 3)})
-    assert set(metrics) == {"psnr", "coarse_psnr", "fine_psnr"} and metrics["psnr"] > 0
-    assert images["img"].shape == (H, 3 * Wd, 3) and images["accumulation"].shape == (H, 2 * Wd, 3)
-    assert images["depth"].shape == (H, 2 * Wd, 3)
+    # -- against the oracle on the whole image (eval: the collider's near plane is reset to 0, N12)
+    near, far = 0.0, cfg.collider_params["far_plane"]
+    with torch.no_grad():
+        ref = cpu_ref.get_outputs(P, cpu_ref.FieldSpec(num_layers=4, width=64), cpu_ref.ModelSpec(*samples), o, d, pa,
+                                  torch.full((n, 1), near), torch.full((n, 1), far), training=False)
+    assert torch.equal(img["mask"].reshape(-1).cpu(), ref["mask"]) and 0 < int(ref["mask"].sum()) < n
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "accumulation_coarse",
+              "accumulation_fine", "diff", "tint", "roughness"):
+        assert img[k].shape[:2] == (H, Wd), k
+        assert max_abs(img[k].reshape(n, -1).cpu(), ref[k]) <= TOL, k
+    for lvl in ("coarse", "fine"):  # median depth: same bin unless the cumulative weight sits on 0.5
+        cw = torch.cumsum(ref[f"weights_{lvl}"][..., 0], dim=-1)
+        near_half = ((cw - 0.5).abs() < 1e-5).any(dim=-1, keepdim=True)
+        bad = ((img[f"depth_{lvl}"].reshape(n, 1).cpu() - ref[f"depth_{lvl}"]).abs() > 1e-4) & ~near_half
+        assert not bool(bad.any()), lvl
+    assert "depth_reflect_fine" not in img  # [M,1] is not an image (SURVEY 3.4)
+    # -- the eval-image hook against plain torch on the CPU (the reference's own raises KeyError at model.py:438)
+    gt = torch.rand(H, Wd, 4, generator=torch.Generator().manual_seed(5))  # RGBA: blended on white like the reference
+    metrics, images = model.get_image_metrics_and_images(img, {"image": gt.to(dev)})
+    c = {k: v.cpu() for k, v in img.items()}
+    gt3 = gt[..., :3] * gt[..., 3:] + (1.0 - gt[..., 3:])
+    rgb_c, rgb_f = c["mid_rgb_coarse"].clip(0, 1), c["mid_reflect_fine"].clip(0, 1)
+    psnr = lambda a, b: 10.0 * math.log10(1.0 / float(((a.double() - b.double()) ** 2).mean()))  # noqa: E731
+    assert set(metrics) == {"psnr", "coarse_psnr", "fine_psnr"}
+    assert abs(metrics["fine_psnr"] - psnr(gt3, rgb_f)) <= 1e-3 and metrics["psnr"] == metrics["fine_psnr"]
+    assert abs(metrics["coarse_psnr"] - psnr(gt3, rgb_c)) <= 1e-3
+    assert max_abs(images["img"].cpu(), torch.cat([gt3, rgb_c, rgb_f], dim=1)) <= 1e-6
+
+    def depth_panel(dep, acc):
+        x = ((dep - cfg.collider_params["near_plane"]) / (far - cfg.collider_params["near_plane"])).clamp(0, 1)
+        return (x * acc + (1 - acc)).expand(H, Wd, 3)
+
+    assert max_abs(images["accumulation"].cpu(), torch.cat([c["accumulation_coarse"].expand(H, Wd, 3),
+                                                           c["accumulation_fine"].expand(H, Wd, 3)], dim=1)) <= 1e-6
+    assert max_abs(images["depth"].cpu(), torch.cat([depth_panel(c["depth_coarse"], c["accumulation_coarse"]),
+                                                    depth_panel(c["depth_fine"], c["accumulation_fine"])], dim=1)) <= 1e-6
 
 
 # ---------------------------------------------------------------------------------------------- edge shapes
