@@ -61,7 +61,13 @@ struct RsnPackedLayout {
   size_t h_enc0, h_enc_skip, h_bh, h_mid_sh, h_mid_x, h_rgb;
   size_t hT_x[RSN_MAX_TRUNK_LAYERS];  // split-bf16 copies of the transposed segments (training sweeps)
   size_t hT_enc0, hT_enc_skip, hT_bh, hT_mid_x, hT_rgb;
+  // RSN_MMA_BF16 at width 256 only: the whole network's bf16 weight fragments (1 KiB = [lane][8 bf16] each) as ONE
+  // linear stream in the exact order rsn_field_bf16_ring_kernel consumes them, in groups of 8 fragments (8 KiB): the
+  // kernel's workgroups pull it through an LDS ring by LDS-DMA (rsn_field_bf16.hip)
+  size_t r_stream;                    // 0 = absent
+  int r_groups;                       // 8-fragment groups per pass over the network
   size_t total;                       // floats
 };
+#define RSN_RING_GROUP_FRAGS 8
 
 int rsn_compute_layout(const rsn_field_desc* desc, RsnPackedLayout* L);

@@ -13,6 +13,8 @@
 // Weights: split 0 of the split-bf16 segments written by rsn_pack_weights ([k16][nb][3][lane][8 bf16]).
 // Slab: X[kk][lane] = 8 bf16 = the lane's features kk*16 + {4h..4h+3} and kk*16 + 8 + {4h..4h+3} (K-iterations 2kk, 2kk+1
 // of the fp32 kernel), so the packed K order is unchanged.
+#include <stdlib.h>
+
 #include "rsn_field_common.h"
 
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
@@ -312,10 +314,394 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_kernel(const FieldArgs 
   }
 }
 
+// ================================================================================================
+// Width 256 (the BASELINE network): the weight stream is SHARED by the workgroup through an LDS ring.
+//
+// The kernel above makes every wave pull its own 1.2 MB of weight fragments per 32-point tile from L1/L2: one 1 KiB
+// fragment per 32-cycle MFMA per SIMD = 128 B/clk/CU, twice what a CU's L1 delivers (round 1: 33 % MFMA-busy, more
+// vector loads than MFMAs).  Here
+//   * the network's fragments form ONE linear stream in consumption order (rsn_pack.hip, L.r_stream), cut into
+//     groups of 8 fragments (8 KiB);
+//   * the four waves of a workgroup walk the network in lockstep and pull the stream through a 5-slot LDS ring by
+//     LDS-DMA (global_load_lds_dwordx4, two 1 KiB pieces per wave and group), 4 groups ahead of the MFMAs; every
+//     fragment is read from L2 once per WORKGROUP and tile (4x less L2 traffic) and feeds the MFMAs by
+//     ds_read_b128 (128 B/clk/CU of the LDS's 256);
+//   * ONE s_barrier per group: behind it group g+1 has landed for every wave and the slot of group g-1 is free for
+//     the DMA of group g+4 (counted s_waitcnt vmcnt: other vector-memory operations only make it stricter);
+//   * activations never touch LDS: a lane's 256 inputs of the next layer are the bf16 pairs of its own accumulators
+//     (same lane-local hand-off as everywhere), kept in 64 VGPRs and indexed statically by the fully unrolled K loop;
+//     the LDS holds only the ring (40 KiB), the encoded inputs for the skip layer (7 KiB per wave) and the biases;
+//   * two workgroups per CU (78 KiB LDS, <= 256 VGPRs): while one encodes or drains accumulators the other's
+//     MFMAs keep the matrix pipe busy.
+// ================================================================================================
+#define RING_SLOTS 5
+#define RING_LEAD 4   // groups in flight ahead of the group being consumed (= RING_SLOTS - 1)
+#define RING_FIFO 4   // fragments read from the ring ahead of their MFMA (registers: 4 x 4 VGPRs)
+#define RING_GROUP_BYTES (RSN_RING_GROUP_FRAGS * 1024)
+#define RING_BYTES (RING_SLOTS * RING_GROUP_BYTES)
+#define RING_STASH_BYTES (RSN_ENC_K16 * 1024)          // per wave: encoded inputs as bf16, [k16][lane][8]
+#define RING_MAX_LAYERS 10                             // trunk depth the LDS bias table is sized for
+#define RING_BIAS_FLOATS (RING_MAX_LAYERS * 256 + 288 + 128 + 32)
+#define RING_LDS_BYTES (RING_BYTES + 4 * RING_STASH_BYTES + RING_BIAS_FLOATS * 4)
+
+struct Ring {
+  const char* src;     // this lane's source pointer into the stream: base + wave * 2 KiB + lane * 16
+  unsigned lds_dst;    // LDS byte address of this wave's two pieces inside slot 0
+  int n_groups;        // stream length in groups
+  int issue_grp, issue_slot;   // next group to fetch and the slot it goes to
+  unsigned rd_base;    // byte offset (inside smem) of this lane's 16 B in fragment 0 of slot 0
+  unsigned rd_cur, rd_next;    // the same for the group being consumed / the one after it
+  int next_slot;
+};
+
+// one LDS-DMA piece: 64 lanes x 16 B from each lane's `gsrc` to LDS [lds_dst, lds_dst + 1 KiB)   (M0 = LDS base)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+__device__ __forceinline__ void ring_issue(Ring& r) {
+  const char* g = r.src + (size_t)r.issue_grp * RING_GROUP_BYTES;
+  const unsigned d = __builtin_amdgcn_readfirstlane(r.lds_dst + (unsigned)r.issue_slot * RING_GROUP_BYTES);
+  glds16(g, d);
+  glds16(g + 1024, d + 1024);
+  r.issue_grp = (r.issue_grp + 1 == r.n_groups) ? 0 : r.issue_grp + 1;
+  r.issue_slot = (r.issue_slot + 1 == RING_SLOTS) ? 0 : r.issue_slot + 1;
+}
+
+// group boundary: the group about to be consumed (and the one after it) are in LDS for every wave; the previous
+// group's slot is refilled.  vmcnt counts in issue order, so "all but the youngest 2*(LEAD-2)" covers every DMA of
+// the two oldest groups in flight.
+__device__ __forceinline__ void ring_sync(Ring& r) {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_LEAD - 2)) : "memory");
+  ring_issue(r);
+  r.rd_cur = r.rd_next;
+  r.next_slot = (r.next_slot + 1 == RING_SLOTS) ? 0 : r.next_slot + 1;
+  r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
+}
+
+// acc[nb] += W-fragment(i) * X[kk] over a GEMM of NBO x KS fragments (a whole number of groups); fragment i of the
+// stream sits in FIFO register i % RING_FIFO when its MFMA issues, and fragment i + RING_FIFO is read meanwhile.
+template <int NBO, int KS, int XN>
+__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[NBO], const bf16x8 (&X)[XN], Ring& r, bf16x8 (&W)[RING_FIFO],
+                                          const char* smem) {
+  static_assert((NBO * KS) % RSN_RING_GROUP_FRAGS == 0 && KS <= XN, "a GEMM is a whole number of ring groups");
+#pragma unroll
+  for (int i = 0; i < NBO * KS; ++i) {
+    if (i % RSN_RING_GROUP_FRAGS == 0) ring_sync(r);
+    const int kk = i / NBO, nb = i % NBO;
+    const bf16x8 wa = W[i % RING_FIFO];
+    const int pos = (i % RSN_RING_GROUP_FRAGS) + RING_FIFO;
+    W[i % RING_FIFO] = *reinterpret_cast<const bf16x8*>(
+        smem + (pos < RSN_RING_GROUP_FRAGS ? r.rd_cur + pos * 1024 : r.rd_next + (pos - RSN_RING_GROUP_FRAGS) * 1024));
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, X[kk], acc[nb], 0, 0, 0);
+  }
+}
+
+// accumulators <- bias (LDS table; all lanes of a half-wave read one address: broadcast)
+template <int NBO>
+__device__ __forceinline__ void init_acc_lds(f32x16 (&acc)[NBO], const float* bias, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
+      acc[nb][4 * q + 0] = bv.x;
+      acc[nb][4 * q + 1] = bv.y;
+      acc[nb][4 * q + 2] = bv.z;
+      acc[nb][4 * q + 3] = bv.w;
+    }
+}
+
+// accumulator blocks 0..NBS-1 -> the next GEMM's B operands: K=16 step nb*2 + qp = registers 8qp..8qp+7 of block nb.
+// With `bias` the block's accumulators restart from the next layer's bias right after they are packed; the
+// sched_barrier keeps hipcc from hoisting all 32 bias loads above the packing (128 extra live registers).
+template <int NBO, int NBS, bool RELU, int XN>
+__device__ __forceinline__ void acc_to_x(f32x16 (&acc)[NBO], bf16x8 (&X)[XN], const float* bias = nullptr, int h = 0) {
+#pragma unroll
+  for (int nb = 0; nb < NBS; ++nb) {
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      uint4v w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = pack2<RELU>(acc[nb][8 * qp + 2 * e], acc[nb][8 * qp + 2 * e + 1]);
+      X[nb * 2 + qp] = __builtin_bit_cast(bf16x8, w);
+    }
+    if (bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
+        acc[nb][4 * q + 0] = bv.x;
+        acc[nb][4 * q + 1] = bv.y;
+        acc[nb][4 * q + 2] = bv.z;
+        acc[nb][4 * q + 3] = bv.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const FieldArgs a) {
+  constexpr int NB = 8, W = 256;
+  __shared__ __attribute__((aligned(1024))) char smem[RING_LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  char* stash = smem + RING_BYTES + wid * RING_STASH_BYTES;         // this wave's encoded inputs
+  bf16x8* ST = reinterpret_cast<bf16x8*>(stash) + lane;             // [k16][lane]
+  __bf16* STs = reinterpret_cast<__bf16*>(ST);                      // element (kk, pos) of this lane: STs[kk*512 + pos]
+  float* bias = reinterpret_cast<float*>(smem + RING_BYTES + 4 * RING_STASH_BYTES);
+  const float* b_bh = bias + RING_MAX_LAYERS * 256;
+  const float* b_mid = b_bh + 288;
+  const float* b_rgb = b_mid + 128;
+
+  int n_rays = a.n_rays;
+  if (a.n_dev) {
+    const int nd = *a.n_dev;
+    n_rays = nd < n_rays ? nd : n_rays;
+  }
+  const long long n_points = (long long)n_rays * a.S;
+  const long long n_tiles = (n_points + 127) / 128;
+  if ((long long)blockIdx.x >= n_tiles) return;  // workgroup-uniform: no barrier is skipped by part of a workgroup
+  const float* __restrict__ pk = a.packed;
+
+  // ---- biases -> LDS (once per workgroup)
+  for (int i = threadIdx.x; i < a.num_layers * 256; i += 256) bias[i] = pk[a.L.b[i >> 8] + (i & 255)];
+  for (int i = threadIdx.x; i < 288; i += 256) bias[RING_MAX_LAYERS * 256 + i] = pk[a.L.b_bh + i];
+  if (threadIdx.x < 128) bias[RING_MAX_LAYERS * 256 + 288 + threadIdx.x] = pk[a.L.b_mid + threadIdx.x];
+  if (threadIdx.x < 32) bias[RING_MAX_LAYERS * 256 + 288 + 128 + threadIdx.x] = pk[a.L.b_rgb + threadIdx.x];
+
+  // ---- the ring: the first RING_LEAD groups are requested, group 0 is awaited, its first fragments are read
+  Ring r;
+  r.src = reinterpret_cast<const char*>(pk + a.L.r_stream) + wid * 2048 + lane * 16;
+  r.lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wid * 2048u;
+  r.n_groups = a.L.r_groups;
+  r.issue_grp = 0;
+  r.issue_slot = 0;
+  r.rd_base = (unsigned)lane * 16u;
+  r.next_slot = 0;
+  r.rd_next = r.rd_base;
+  r.rd_cur = r.rd_base;
+  __syncthreads();  // nothing in flight yet: a plain barrier (also publishes the bias table)
+#pragma unroll
+  for (int g = 0; g < RING_LEAD; ++g) ring_issue(r);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_LEAD - 1)) : "memory");
+  bf16x8 Wf[RING_FIFO];
+#pragma unroll
+  for (int j = 0; j < RING_FIFO; ++j) Wf[j] = *reinterpret_cast<const bf16x8*>(smem + r.rd_next + j * 1024);
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long p0 = tile * 128 + wid * 32;
+    // every wave walks every tile (the barriers and the DMA shares are per wave); a wave past the end recomputes the
+    // last point and stores nothing
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque per-tile lane id: per-lane addresses are not hoisted out of the tile loop
+    const int m = ln & 31, h = ln >> 5;
+    const long long p = p0 + m;
+    const bool valid = p < n_points;
+    const long long pc = valid ? p : n_points - 1;
+
+    float mc[3] = {0.0f, 0.0f, 0.0f}, vc[3] = {0.0f, 0.0f, 0.0f}, vd[3] = {0.0f, 0.0f, 0.0f};
+    bool has_cov = true, has_dir = true;
+    // ---------------- encode (fp32, as rsn_field.hip) into this wave's stash -----------------
+    if (a.mode == RSN_MODE_FRUSTUM) {
+      const long long ray = pc / a.S;
+      const int s = (int)(pc - ray * a.S);
+      float o[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o[c] = a.origins[ray * 3 + c];
+        vd[c] = a.directions[ray * 3 + c];
+      }
+      const float pa = a.pixel_area[ray];
+      const float t0 = a.bins[ray * (a.S + 1) + s];
+      const float t1 = a.bins[ray * (a.S + 1) + s + 1];
+      frustum_to_contracted(o, vd, pa, t0, t1, mc, vc);
+    } else if (a.mode == RSN_MODE_INF) {
+      const float r2 = a.sqradius[pc];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        vd[c] = a.directions[pc * 3 + c];
+        mc[c] = 2.0f * vd[c];
+        vc[c] = (0.6f * r2) * (1.0f - vd[c] * vd[c]);
+      }
+      has_dir = false;  // SH inputs are zeroed (reflect_sampling_nerf_field.py:199)
+    } else {
+      has_cov = a.cov_diag != nullptr;
+      has_dir = a.view_dirs != nullptr;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        mc[c] = a.means[pc * 3 + c];
+        vc[c] = has_cov ? a.cov_diag[pc * 3 + c] : 0.0f;
+        vd[c] = has_dir ? a.view_dirs[pc * 3 + c] : 0.0f;
+      }
+    }
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      const float x = (c == 0) ? mc[0] : (c == 1 ? mc[1] : mc[2]);
+      const float v = (c == 0) ? vc[0] : (c == 1 ? vc[1] : vc[2]);
+      const float sx = 6.283185307179586f * x;
+#pragma unroll 2
+      for (int jj = 0; jj < 8; ++jj) {
+        const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
+        const float ang = sx * f;
+        const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
+        const float fs = e * sin_big(ang);
+        const float fc = e * sin_big(ang + 1.5707963267948966f);
+        const int u = c * 8 + jj, u2 = u + 24;
+        STs[(u >> 3) * 512 + ((u >> 2) & 1) * 4 + (u & 3)] = (__bf16)fs;
+        STs[(u2 >> 3) * 512 + ((u2 >> 2) & 1) * 4 + (u2 & 3)] = (__bf16)fc;
+      }
+    }
+    {
+      const float rw[8] = {h == 0 ? mc[0] : 0.0f, h == 0 ? mc[1] : 0.0f, h == 0 ? mc[2] : 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      ST[6 * 64] = pack8(rw);
+    }
+
+    bf16x8 X[16];
+    // ---------------- trunk -----------------
+    {
+      f32x16 acc[NB];
+      init_acc_lds<NB>(acc, bias, h);
+#pragma unroll
+      for (int kk = 0; kk < RSN_ENC_K16; ++kk) X[kk] = ST[kk * 64];
+      gemm_ring<NB, RSN_ENC_K16, 16>(acc, X, r, Wf, smem);
+#pragma unroll 1
+      for (int l = 1; l < a.num_layers; ++l) {
+        acc_to_x<NB, NB, true, 16>(acc, X, bias + l * 256, h);
+        gemm_ring<NB, 16, 16>(acc, X, r, Wf, smem);
+        if (l == a.skip_layer) {
+          bf16x8 XE[RSN_ENC_K16];
+#pragma unroll
+          for (int kk = 0; kk < RSN_ENC_K16; ++kk) XE[kk] = ST[kk * 64];
+          gemm_ring<NB, RSN_ENC_K16, RSN_ENC_K16>(acc, XE, r, Wf, smem);
+        }
+      }
+      acc_to_x<NB, NB, true, 16>(acc, X);  // out_activation = ReLU: the embedding
+    }
+    if (a.embedding && valid) {  // the embedding as the downstream GEMMs see it (bf16-rounded)
+#pragma unroll
+      for (int kk = 0; kk < NB * 2; ++kk) {
+        const bf16x8 f = X[kk];
+        *reinterpret_cast<float4*>(a.embedding + pc * W + kk * 16 + 4 * h) =
+            make_float4((float)f[0], (float)f[1], (float)f[2], (float)f[3]);
+        *reinterpret_cast<float4*>(a.embedding + pc * W + kk * 16 + 8 + 4 * h) =
+            make_float4((float)f[4], (float)f[5], (float)f[6], (float)f[7]);
+      }
+    }
+
+    // ---------------- heads (one 32-row block), then the bottleneck -----------------
+    float dcol[3], tcol[3], rho;
+    {
+      f32x16 acch[1];
+      init_acc_lds<1>(acch, b_bh + 256, h);
+      gemm_ring<1, 16, 16>(acch, X, r, Wf, smem);
+      const float r0 = acch[0][0], r1 = acch[0][1], r2 = acch[0][2], r3 = acch[0][3];
+      const float r4 = acch[0][4], r5 = acch[0][5], r6 = acch[0][6];
+      // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
+      const float rough_raw = __shfl(r4, m, 64);
+      rho = softplus_f(rough_raw);
+      dcol[0] = sigmoid_f(r0); dcol[1] = sigmoid_f(r1); dcol[2] = sigmoid_f(r2);
+      tcol[0] = sigmoid_f(r4); tcol[1] = sigmoid_f(r5); tcol[2] = sigmoid_f(r6);
+      if (a.mode != RSN_MODE_INF && valid) {
+        if (h == 0) {
+          float nrm = fmaxf(sqrtf(r1 * r1 + r2 * r2 + r3 * r3), 1e-12f);
+          float nx = -(r1 / nrm), ny = -(r2 / nrm), nz = -(r3 / nrm);
+          nrm = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
+          nx /= nrm; ny /= nrm; nz /= nrm;
+          if (a.out.sigma) a.out.sigma[pc] = softplus_f(r0 + a.density_bias);
+          if (a.out.raw_density) a.out.raw_density[pc] = r0;
+          if (a.out.pred_normals) {
+            a.out.pred_normals[pc * 3 + 0] = nx;
+            a.out.pred_normals[pc * 3 + 1] = ny;
+            a.out.pred_normals[pc * 3 + 2] = nz;
+          }
+          if (a.out.n_dot_d) a.out.n_dot_d[pc] = vd[0] * nx + vd[1] * ny + vd[2] * nz;
+          if (a.out.roughness) a.out.roughness[pc] = sigmoid_f(r4);
+          if (a.out.raw_roughness) a.out.raw_roughness[pc] = r4;
+        } else {
+          if (a.out.diff) {
+            a.out.diff[pc * 3 + 0] = dcol[0]; a.out.diff[pc * 3 + 1] = dcol[1]; a.out.diff[pc * 3 + 2] = dcol[2];
+          }
+          if (a.out.tint) {
+            a.out.tint[pc * 3 + 0] = tcol[0]; a.out.tint[pc * 3 + 1] = tcol[1]; a.out.tint[pc * 3 + 2] = tcol[2];
+          }
+        }
+      }
+    }
+    {
+      f32x16 acc[NB];
+      init_acc_lds<NB>(acc, b_bh, h);
+      gemm_ring<NB, 16, 16>(acc, X, r, Wf, smem);
+      acc_to_x<NB, NB, false, 16>(acc, X);  // bottleneck output (no activation): the x-part of mlp_mid's input
+    }
+
+    // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
+    bf16x8 XS[4];
+    {
+      float sh[34];
+      if (has_dir) {
+        sh34_attenuated(vd[0], vd[1], vd[2], rho, sh);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 34; ++i) sh[i] = 0.0f;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {  // slot u = it*4 + s holds component 17h + u (u < 17); K=16 step 3 is padding
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int u = (2 * kk + (e >> 2)) * 4 + (e & 3);
+          v[e] = (u < 17) ? (h ? sh[17 + (u < 17 ? u : 0)] : sh[u < 17 ? u : 0]) : 0.0f;
+        }
+        XS[kk] = pack8(v);
+      }
+    }
+
+    // ---------------- mlp_mid + RGB head -----------------
+    {
+      f32x16 accm[4];
+      init_acc_lds<4>(accm, b_mid, h);
+      gemm_ring<4, 4, 4>(accm, XS, r, Wf, smem);
+      gemm_ring<4, 16, 16>(accm, X, r, Wf, smem);
+      acc_to_x<4, 4, true, 16>(accm, X);  // hidden (128): K=16 steps 0..7
+    }
+    {
+      f32x16 accr[1];
+      init_acc_lds<1>(accr, b_rgb, h);
+      gemm_ring<1, 8, 16>(accr, X, r, Wf, smem);
+      if (h == 1 && valid && a.out.color) {
+        const float m0 = sigmoid_f(accr[0][0]);
+        const float m1 = sigmoid_f(accr[0][1]);
+        const float m2 = sigmoid_f(accr[0][2]);
+        if (a.mode == RSN_MODE_INF) {
+          a.out.color[pc * 3 + 0] = m0; a.out.color[pc * 3 + 1] = m1; a.out.color[pc * 3 + 2] = m2;
+        } else {
+          a.out.color[pc * 3 + 0] = dcol[0] + tcol[0] * m0;
+          a.out.color[pc * 3 + 1] = dcol[1] + tcol[1] * m1;
+          a.out.color[pc * 3 + 2] = dcol[2] + tcol[2] * m2;
+        }
+      }
+    }
+  }
+  // no LDS-DMA may outlive the workgroup's LDS allocation
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // called by launch_field (rsn_field.hip) for RSN_MMA_BF16 eval launches
 int rsn_launch_field_bf16(int width, long long grid, hipStream_t st, const FieldArgs& a) {
+  static const bool per_wave_stream = getenv("RSN_BF16_PER_WAVE_STREAM") != nullptr;  // A/B switch for tools/
   switch (width) {
-    case 256: hipLaunchKernelGGL((rsn_field_bf16_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
+    case 256:
+      // full network evaluations run on the shared LDS weight ring; the granular heads-only mode (a caller-supplied
+      // embedding skips the trunk, i.e. most of the stream) keeps the per-wave stream
+      if (a.mode != RSN_MODE_EMB && a.L.r_stream != 0 && a.num_layers <= RING_MAX_LAYERS && !per_wave_stream)
+        hipLaunchKernelGGL(rsn_field_bf16_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((rsn_field_bf16_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      break;
     case 128: hipLaunchKernelGGL((rsn_field_bf16_kernel<4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
     case 64: hipLaunchKernelGGL((rsn_field_bf16_kernel<2>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
     default: RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "width=%d unsupported", width);

@@ -127,6 +127,13 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   off += (size_t)(L->nbm * 2) * L->nb * 3 * blk;
   L->hT_rgb = off;
   off += (size_t)2 * L->nbm * 3 * blk;
+  if (d->mma_mode == RSN_MMA_BF16 && d->width == 256) {
+    // enc0 7 K-steps x 8 blocks; x layers 16 x 8; enc_skip 7 x 8; heads 16 x 1; bottleneck 16 x 8; mlp_mid SH part
+    // 3 (padded to 4) x 4; mlp_mid x part 16 x 4; rgb 8 x 1 -- every GEMM a whole number of 8-fragment groups
+    L->r_groups = RSN_ENC_K16 + (d->num_layers - 1) * 16 + (d->skip_layer >= 1 ? RSN_ENC_K16 : 0) + 2 + 16 + 2 + 8 + 1;
+    L->r_stream = off;
+    off += (size_t)L->r_groups * RSN_RING_GROUP_FRAGS * blk;
+  }
   L->total = off;
   return RSN_OK;
 }
@@ -209,6 +216,33 @@ __global__ void rsn_pack_split_kernel(const float* __restrict__ src, int n_it, i
   dst[((base + 0) * 64 + lane) * 8 + ee] = b1;
   dst[((base + 1) * 64 + lane) * 8 + ee] = b2;
   dst[((base + 2) * 64 + lane) * 8 + ee] = b3;
+}
+
+// ---- ring stream (RSN_MMA_BF16, width 256): split-0 fragments of the h_* segments re-ordered into consumption order
+#define RING_MAX_PIECES 40
+struct RingPiece {
+  unsigned src;      // float offset of the split-bf16 source segment ([k16][nbo_src][3][lane][8 bf16])
+  short nbo_src, nb0, nbo, ks_real, ks;
+  int frag0;         // first fragment of this piece in the stream
+};
+struct RingJob {
+  const float* packed;
+  float* dst;
+  int n_pieces, n_frags;
+  RingPiece p[RING_MAX_PIECES];
+};
+
+__global__ void rsn_pack_ring_kernel(const RingJob job) {  // one 64-thread workgroup per 1 KiB fragment
+  const int f = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < job.n_pieces && job.p[pi + 1].frag0 <= f) ++pi;
+  const RingPiece pc = job.p[pi];
+  const int i = f - pc.frag0;
+  const int kk = i / pc.nbo, nb = pc.nb0 + i % pc.nbo;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (kk < pc.ks_real)
+    v = reinterpret_cast<const uint4*>(job.packed + pc.src + ((size_t)(kk * pc.nbo_src + nb) * 3) * 256)[threadIdx.x];
+  reinterpret_cast<uint4*>(job.dst + (size_t)f * 256)[threadIdx.x] = v;
 }
 
 namespace {
@@ -467,5 +501,33 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   if ((rc = split_seg(packed + L.wT_mid_x, NBM * 4, NB, packed + L.hT_mid_x, st)) != RSN_OK) return rc;
   if ((rc = split_seg(packed + L.w_rgb, NBM * 4, 1, packed + L.h_rgb, st)) != RSN_OK) return rc;
   if ((rc = split_seg(packed + L.wT_rgb, 4, NBM, packed + L.hT_rgb, st)) != RSN_OK) return rc;
+  if (L.r_stream != 0) {
+    RingJob rj;
+    memset(&rj, 0, sizeof(rj));
+    rj.packed = packed;
+    rj.dst = packed + L.r_stream;
+    int frag = 0;
+    auto piece = [&](size_t src, int nbo_src, int nb0, int nbo, int ks_real, int ks) {
+      RingPiece& q = rj.p[rj.n_pieces++];
+      q.src = (unsigned)src; q.nbo_src = (short)nbo_src; q.nb0 = (short)nb0; q.nbo = (short)nbo;
+      q.ks_real = (short)ks_real; q.ks = (short)ks; q.frag0 = frag;
+      frag += ks * nbo;
+    };
+    piece(L.h_enc0, NB, 0, NB, RSN_ENC_K16, RSN_ENC_K16);
+    for (int l = 1; l < d->num_layers; ++l) {
+      piece(L.h_x[l], NB, 0, NB, NB * 2, NB * 2);
+      if (l == d->skip_layer) piece(L.h_enc_skip, NB, 0, NB, RSN_ENC_K16, RSN_ENC_K16);
+    }
+    piece(L.h_bh, NB + 1, NB, 1, NB * 2, NB * 2);  // heads block first (its epilogue feeds the SH encoding)
+    piece(L.h_bh, NB + 1, 0, NB, NB * 2, NB * 2);  // bottleneck
+    piece(L.h_mid_sh, NBM, 0, NBM, RSN_SH_K16, 4);
+    piece(L.h_mid_x, NBM, 0, NBM, NB * 2, NB * 2);
+    piece(L.h_rgb, 1, 0, 1, NBM * 2, NBM * 2);
+    RSN_REQUIRE(rj.n_pieces <= RING_MAX_PIECES && frag == L.r_groups * RSN_RING_GROUP_FRAGS, RSN_ERR_INVALID_ARGUMENT,
+                "ring stream: %d fragments in %d pieces, layout says %d groups", frag, rj.n_pieces, L.r_groups);
+    rj.n_frags = frag;
+    hipLaunchKernelGGL(rsn_pack_ring_kernel, dim3((unsigned)frag), dim3(64), 0, st, rj);
+    RSN_HIP(hipGetLastError());
+  }
   return RSN_OK;
 }

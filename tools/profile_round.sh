@@ -14,8 +14,8 @@ OUT=/root/repo/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 /root/repo/bench.py --no-cpu-baseline $EXTRA"
-P="$B --no-train-leg"  # counter passes: headline kernels only
+B="python3 /root/repo/bench.py --no-cpu-baseline --no-secondary $EXTRA"
+P="$B"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B --steps 20 --warmup 5 > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $P --steps 5 --warmup 2 > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $P --steps 5 --warmup 2 > $OUT/pmc_write.log 2>&1 || exit 1
