@@ -334,19 +334,27 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_kernel(const FieldArgs 
 //   * two workgroups per CU (78 KiB LDS, <= 256 VGPRs): while one encodes or drains accumulators the other's
 //     MFMAs keep the matrix pipe busy.
 // ================================================================================================
-#define RING_SLOTS 5
-#define RING_LEAD 4   // groups in flight ahead of the group being consumed (= RING_SLOTS - 1)
 #define RING_FIFO 4   // fragments read from the ring ahead of their MFMA (registers: 4 x 4 VGPRs)
 #define RING_GROUP_BYTES (RSN_RING_GROUP_FRAGS * 1024)
-#define RING_BYTES (RING_SLOTS * RING_GROUP_BYTES)
 #define RING_STASH_BYTES (RSN_ENC_K16 * 1024)          // per wave: encoded inputs as bf16, [k16][lane][8]
 #define RING_MAX_LAYERS 10                             // trunk depth the LDS bias table is sized for
 #define RING_BIAS_FLOATS (RING_MAX_LAYERS * 256 + 288 + 128 + 32)
-#define RING_LDS_BYTES (RING_BYTES + 4 * RING_STASH_BYTES + RING_BIAS_FLOATS * 4)
+
+// NW = waves per workgroup.  4: two workgroups per CU, 5-slot ring each (78 KiB);  8: one workgroup per CU whose two
+// waves per SIMD share ONE stream (half the LDS-DMA pieces per MFMA, half the L2 traffic), 8-slot ring (130 KiB).
+template <int NW>
+struct RingCfg {
+  static constexpr int SLOTS = NW == 8 ? 8 : 5;
+  static constexpr int LEAD = SLOTS - 1;              // groups in flight ahead of the group being consumed
+  static constexpr int PPW = RSN_RING_GROUP_FRAGS / NW;  // LDS-DMA pieces per wave and group
+  static constexpr int RING_BYTES = SLOTS * RING_GROUP_BYTES;
+  static constexpr int LDS_BYTES = RING_BYTES + NW * RING_STASH_BYTES + RING_BIAS_FLOATS * 4;
+};
 
 struct Ring {
-  const char* src;     // this lane's source pointer into the stream: base + wave * 2 KiB + lane * 16
-  unsigned lds_dst;    // LDS byte address of this wave's two pieces inside slot 0
+  const char* src;     // wave-uniform source pointer into the stream: base + wave * PPW KiB (the lane adds lane * 16)
+  unsigned lane16;     // lane * 16
+  unsigned lds_dst;    // LDS byte address of this wave's pieces inside slot 0
   int n_groups;        // stream length in groups
   int issue_grp, issue_slot;   // next group to fetch and the slot it goes to
   unsigned rd_base;    // byte offset (inside smem) of this lane's 16 B in fragment 0 of slot 0
@@ -354,50 +362,69 @@ struct Ring {
   int next_slot;
 };
 
-// one LDS-DMA piece: 64 lanes x 16 B from each lane's `gsrc` to LDS [lds_dst, lds_dst + 1 KiB)   (M0 = LDS base)
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// one LDS-DMA piece: 64 lanes x 16 B from gbase + voff (scalar base + 32-bit lane offset: half the address data of the
+// 64-bit-VGPR form goes through the vector-memory issue path) to LDS [lds_dst, lds_dst + 1 KiB)   (M0 = LDS base)
+__device__ __forceinline__ void glds16(const void* gbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
+               : "v"(voff), "s"(gbase), "s"(lds_dst)
                : "memory");
 }
 
+template <int NW>
 __device__ __forceinline__ void ring_issue(Ring& r) {
   const char* g = r.src + (size_t)r.issue_grp * RING_GROUP_BYTES;
   const unsigned d = __builtin_amdgcn_readfirstlane(r.lds_dst + (unsigned)r.issue_slot * RING_GROUP_BYTES);
-  glds16(g, d);
-  glds16(g + 1024, d + 1024);
+#pragma unroll
+  for (int i = 0; i < RingCfg<NW>::PPW; ++i) glds16(g + i * 1024, r.lane16, d + i * 1024);
   r.issue_grp = (r.issue_grp + 1 == r.n_groups) ? 0 : r.issue_grp + 1;
-  r.issue_slot = (r.issue_slot + 1 == RING_SLOTS) ? 0 : r.issue_slot + 1;
+  r.issue_slot = (r.issue_slot + 1 == RingCfg<NW>::SLOTS) ? 0 : r.issue_slot + 1;
 }
 
 // group boundary: the group about to be consumed (and the one after it) are in LDS for every wave; the previous
-// group's slot is refilled.  vmcnt counts in issue order, so "all but the youngest 2*(LEAD-2)" covers every DMA of
+// group's slot is refilled.  vmcnt counts in issue order, so "all but the youngest PPW*(LEAD-2)" covers every DMA of
 // the two oldest groups in flight.
+// (RSN_RING_NO_*: timing diagnostics of tools/variant_bench.py -- wrong results by construction, never in librsn_hip.so)
+template <int NW>
 __device__ __forceinline__ void ring_sync(Ring& r) {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_LEAD - 2)) : "memory");
-  ring_issue(r);
+#ifdef RSN_RING_NO_BARRIER
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RingCfg<NW>::PPW * (RingCfg<NW>::LEAD - 2)) : "memory");
+#elif defined(RSN_RING_NO_WAIT)
+  asm volatile("s_barrier" ::: "memory");
+#else
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RingCfg<NW>::PPW * (RingCfg<NW>::LEAD - 2)) : "memory");
+#endif
+#ifndef RSN_RING_NO_DMA
+  ring_issue<NW>(r);
+#endif
   r.rd_cur = r.rd_next;
-  r.next_slot = (r.next_slot + 1 == RING_SLOTS) ? 0 : r.next_slot + 1;
+  r.next_slot = (r.next_slot + 1 == RingCfg<NW>::SLOTS) ? 0 : r.next_slot + 1;
   r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
 }
 
 // acc[nb] += W-fragment(i) * X[kk] over a GEMM of NBO x KS fragments (a whole number of groups); fragment i of the
 // stream sits in FIFO register i % RING_FIFO when its MFMA issues, and fragment i + RING_FIFO is read meanwhile.
-template <int NBO, int KS, int XN>
+template <int NW, int NBO, int KS, int XN>
 __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[NBO], const bf16x8 (&X)[XN], Ring& r, bf16x8 (&W)[RING_FIFO],
                                           const char* smem) {
   static_assert((NBO * KS) % RSN_RING_GROUP_FRAGS == 0 && KS <= XN, "a GEMM is a whole number of ring groups");
 #pragma unroll
   for (int i = 0; i < NBO * KS; ++i) {
-    if (i % RSN_RING_GROUP_FRAGS == 0) ring_sync(r);
+    if (i % RSN_RING_GROUP_FRAGS == 0) ring_sync<NW>(r);
     const int kk = i / NBO, nb = i % NBO;
     const bf16x8 wa = W[i % RING_FIFO];
     const int pos = (i % RSN_RING_GROUP_FRAGS) + RING_FIFO;
     W[i % RING_FIFO] = *reinterpret_cast<const bf16x8*>(
         smem + (pos < RSN_RING_GROUP_FRAGS ? r.rd_cur + pos * 1024 : r.rd_next + (pos - RSN_RING_GROUP_FRAGS) * 1024));
+#ifdef RSN_RING_NO_MFMA
+    acc[nb][i % 16] += (float)wa[0] * (float)X[kk][0];
+#else
     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, X[kk], acc[nb], 0, 0, 0);
+#endif
+    // keep the source order (read of fragment i + FIFO, then the MFMA of fragment i): hipcc otherwise sinks the reads
+    // to one or two MFMAs ahead of their use and every other MFMA waits out the LDS latency
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -444,15 +471,19 @@ __device__ __forceinline__ void acc_to_x(f32x16 (&acc)[NBO], bf16x8 (&X)[XN], co
   }
 }
 
-__global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const FieldArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const FieldArgs a) {
   constexpr int NB = 8, W = 256;
-  __shared__ __attribute__((aligned(1024))) char smem[RING_LDS_BYTES];
+  constexpr int RING_BYTES = RingCfg<NW>::RING_BYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[RingCfg<NW>::LDS_BYTES];
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  // wave index as a SCALAR: everything derived from it (this wave's first point of a tile, the running output
+  // addresses hipcc strength-reduces out of the tile loop) then lives in SGPRs instead of 13 spilled VGPR pairs
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* stash = smem + RING_BYTES + wid * RING_STASH_BYTES;         // this wave's encoded inputs
   bf16x8* ST = reinterpret_cast<bf16x8*>(stash) + lane;             // [k16][lane]
   __bf16* STs = reinterpret_cast<__bf16*>(ST);                      // element (kk, pos) of this lane: STs[kk*512 + pos]
-  float* bias = reinterpret_cast<float*>(smem + RING_BYTES + 4 * RING_STASH_BYTES);
+  float* bias = reinterpret_cast<float*>(smem + RING_BYTES + NW * RING_STASH_BYTES);
   const float* b_bh = bias + RING_MAX_LAYERS * 256;
   const float* b_mid = b_bh + 288;
   const float* b_rgb = b_mid + 128;
@@ -462,21 +493,28 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
     const int nd = *a.n_dev;
     n_rays = nd < n_rays ? nd : n_rays;
   }
-  const long long n_points = (long long)n_rays * a.S;
-  const long long n_tiles = (n_points + 127) / 128;
-  if ((long long)blockIdx.x >= n_tiles) return;  // workgroup-uniform: no barrier is skipped by part of a workgroup
+  // 32-bit point indices (the launcher sends batches of 2^31 points or more to the per-wave-stream kernel): no 64-bit
+  // division per lane, fewer loop-invariant registers
+  const unsigned n_points = (unsigned)n_rays * (unsigned)a.S;
+  const unsigned n_tiles = (n_points + NW * 32 - 1) / (NW * 32);
+  if (blockIdx.x >= n_tiles) return;  // workgroup-uniform: no barrier is skipped by part of a workgroup
+  // Every workgroup streams the SAME 1.2 MB in the same order: started together, the 32 CUs of an XCD ask their L2 for
+  // the same lines at the same moment.  A start delay that grows with the workgroup's index inside its XCD
+  // (blockIdx / 8: workgroups are dealt round-robin over the 8 XCDs) spreads the CUs over the stream.
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 31) * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   const float* __restrict__ pk = a.packed;
 
   // ---- biases -> LDS (once per workgroup)
-  for (int i = threadIdx.x; i < a.num_layers * 256; i += 256) bias[i] = pk[a.L.b[i >> 8] + (i & 255)];
-  for (int i = threadIdx.x; i < 288; i += 256) bias[RING_MAX_LAYERS * 256 + i] = pk[a.L.b_bh + i];
+  for (int i = threadIdx.x; i < a.num_layers * 256; i += NW * 64) bias[i] = pk[a.L.b[i >> 8] + (i & 255)];
+  for (int i = threadIdx.x; i < 288; i += NW * 64) bias[RING_MAX_LAYERS * 256 + i] = pk[a.L.b_bh + i];
   if (threadIdx.x < 128) bias[RING_MAX_LAYERS * 256 + 288 + threadIdx.x] = pk[a.L.b_mid + threadIdx.x];
   if (threadIdx.x < 32) bias[RING_MAX_LAYERS * 256 + 288 + 128 + threadIdx.x] = pk[a.L.b_rgb + threadIdx.x];
 
-  // ---- the ring: the first RING_LEAD groups are requested, group 0 is awaited, its first fragments are read
+  // ---- the ring: the first LEAD groups are requested, group 0 is awaited, its first fragments are read
   Ring r;
-  r.src = reinterpret_cast<const char*>(pk + a.L.r_stream) + wid * 2048 + lane * 16;
-  r.lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wid * 2048u;
+  r.src = reinterpret_cast<const char*>(pk + a.L.r_stream) + wid * (RingCfg<NW>::PPW * 1024);
+  r.lane16 = (unsigned)lane * 16u;
+  r.lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wid * (RingCfg<NW>::PPW * 1024u);
   r.n_groups = a.L.r_groups;
   r.issue_grp = 0;
   r.issue_slot = 0;
@@ -486,29 +524,30 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
   r.rd_cur = r.rd_base;
   __syncthreads();  // nothing in flight yet: a plain barrier (also publishes the bias table)
 #pragma unroll
-  for (int g = 0; g < RING_LEAD; ++g) ring_issue(r);
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_LEAD - 1)) : "memory");
+  for (int g = 0; g < RingCfg<NW>::LEAD; ++g) ring_issue<NW>(r);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RingCfg<NW>::PPW * (RingCfg<NW>::LEAD - 1)) : "memory");
   bf16x8 Wf[RING_FIFO];
 #pragma unroll
   for (int j = 0; j < RING_FIFO; ++j) Wf[j] = *reinterpret_cast<const bf16x8*>(smem + r.rd_next + j * 1024);
 
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long p0 = tile * 128 + wid * 32;
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const unsigned p0 = tile * (NW * 32) + wid * 32;
     // every wave walks every tile (the barriers and the DMA shares are per wave); a wave past the end recomputes the
     // last point and stores nothing
     int ln = lane;
     asm volatile("" : "+v"(ln));  // opaque per-tile lane id: per-lane addresses are not hoisted out of the tile loop
     const int m = ln & 31, h = ln >> 5;
-    const long long p = p0 + m;
+    const unsigned p = p0 + m;
     const bool valid = p < n_points;
-    const long long pc = valid ? p : n_points - 1;
+    const size_t pc = valid ? p : n_points - 1;
 
     float mc[3] = {0.0f, 0.0f, 0.0f}, vc[3] = {0.0f, 0.0f, 0.0f}, vd[3] = {0.0f, 0.0f, 0.0f};
     bool has_cov = true, has_dir = true;
     // ---------------- encode (fp32, as rsn_field.hip) into this wave's stash -----------------
     if (a.mode == RSN_MODE_FRUSTUM) {
-      const long long ray = pc / a.S;
-      const int s = (int)(pc - ray * a.S);
+      const unsigned rayu = (unsigned)pc / (unsigned)a.S;
+      const int s = (int)((unsigned)pc - rayu * (unsigned)a.S);
+      const size_t ray = rayu;
       float o[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -538,8 +577,12 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
         vd[c] = has_dir ? a.view_dirs[pc * 3 + c] : 0.0f;
       }
     }
+#ifdef RSN_RING_NO_ENCODE
+    for (int c = 0; c < 0; ++c) {
+#else
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
+#endif
       const float x = (c == 0) ? mc[0] : (c == 1 ? mc[1] : mc[2]);
       const float v = (c == 0) ? vc[0] : (c == 1 ? vc[1] : vc[2]);
       const float sx = 6.283185307179586f * x;
@@ -547,7 +590,8 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
       for (int jj = 0; jj < 8; ++jj) {
         const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
         const float ang = sx * f;
-        const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
+        // exp by v_exp_f32 (2^x): ~1e-6 relative on a feature that is rounded to bf16 (2^-9) next
+        const float e = has_cov ? __builtin_amdgcn_exp2f((-0.5f * (v * (f * f))) * 1.4426950408889634f) : 1.0f;
         const float fs = e * sin_big(ang);
         const float fc = e * sin_big(ang + 1.5707963267948966f);
         const int u = c * 8 + jj, u2 = u + 24;
@@ -567,16 +611,16 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
       init_acc_lds<NB>(acc, bias, h);
 #pragma unroll
       for (int kk = 0; kk < RSN_ENC_K16; ++kk) X[kk] = ST[kk * 64];
-      gemm_ring<NB, RSN_ENC_K16, 16>(acc, X, r, Wf, smem);
+      gemm_ring<NW, NB, RSN_ENC_K16, 16>(acc, X, r, Wf, smem);
 #pragma unroll 1
       for (int l = 1; l < a.num_layers; ++l) {
         acc_to_x<NB, NB, true, 16>(acc, X, bias + l * 256, h);
-        gemm_ring<NB, 16, 16>(acc, X, r, Wf, smem);
+        gemm_ring<NW, NB, 16, 16>(acc, X, r, Wf, smem);
         if (l == a.skip_layer) {
           bf16x8 XE[RSN_ENC_K16];
 #pragma unroll
           for (int kk = 0; kk < RSN_ENC_K16; ++kk) XE[kk] = ST[kk * 64];
-          gemm_ring<NB, RSN_ENC_K16, RSN_ENC_K16>(acc, XE, r, Wf, smem);
+          gemm_ring<NW, NB, RSN_ENC_K16, RSN_ENC_K16>(acc, XE, r, Wf, smem);
         }
       }
       acc_to_x<NB, NB, true, 16>(acc, X);  // out_activation = ReLU: the embedding
@@ -597,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
     {
       f32x16 acch[1];
       init_acc_lds<1>(acch, b_bh + 256, h);
-      gemm_ring<1, 16, 16>(acch, X, r, Wf, smem);
+      gemm_ring<NW, 1, 16, 16>(acch, X, r, Wf, smem);
       const float r0 = acch[0][0], r1 = acch[0][1], r2 = acch[0][2], r3 = acch[0][3];
       const float r4 = acch[0][4], r5 = acch[0][5], r6 = acch[0][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
@@ -631,15 +675,9 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
         }
       }
     }
-    {
-      f32x16 acc[NB];
-      init_acc_lds<NB>(acc, b_bh, h);
-      gemm_ring<NB, 16, 16>(acc, X, r, Wf, smem);
-      acc_to_x<NB, NB, false, 16>(acc, X);  // bottleneck output (no activation): the x-part of mlp_mid's input
-    }
-
     // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
-    bf16x8 XS[4];
+    // computed HERE, while only the embedding (64 VGPRs) is live, and parked in this wave's stash (free since the skip
+    // layer): it costs the bottleneck GEMM below no registers
     {
       float sh[34];
       if (has_dir) {
@@ -656,22 +694,31 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_ring_kernel(const Field
           const int u = (2 * kk + (e >> 2)) * 4 + (e & 3);
           v[e] = (u < 17) ? (h ? sh[17 + (u < 17 ? u : 0)] : sh[u < 17 ? u : 0]) : 0.0f;
         }
-        XS[kk] = pack8(v);
+        ST[kk * 64] = pack8(v);
       }
+    }
+    {
+      f32x16 acc[NB];
+      init_acc_lds<NB>(acc, b_bh, h);
+      gemm_ring<NW, NB, 16, 16>(acc, X, r, Wf, smem);
+      acc_to_x<NB, NB, false, 16>(acc, X);  // bottleneck output (no activation): the x-part of mlp_mid's input
     }
 
     // ---------------- mlp_mid + RGB head -----------------
     {
       f32x16 accm[4];
       init_acc_lds<4>(accm, b_mid, h);
-      gemm_ring<4, 4, 4>(accm, XS, r, Wf, smem);
-      gemm_ring<4, 16, 16>(accm, X, r, Wf, smem);
+      bf16x8 XS[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) XS[kk] = ST[kk * 64];
+      gemm_ring<NW, 4, 4, 4>(accm, XS, r, Wf, smem);
+      gemm_ring<NW, 4, 16, 16>(accm, X, r, Wf, smem);
       acc_to_x<4, 4, true, 16>(accm, X);  // hidden (128): K=16 steps 0..7
     }
     {
       f32x16 accr[1];
       init_acc_lds<1>(accr, b_rgb, h);
-      gemm_ring<1, 8, 16>(accr, X, r, Wf, smem);
+      gemm_ring<NW, 1, 8, 16>(accr, X, r, Wf, smem);
       if (h == 1 && valid && a.out.color) {
         const float m0 = sigmoid_f(accr[0][0]);
         const float m1 = sigmoid_f(accr[0][1]);
@@ -697,8 +744,21 @@ int rsn_launch_field_bf16(int width, long long grid, hipStream_t st, const Field
     case 256:
       // full network evaluations run on the shared LDS weight ring; the granular heads-only mode (a caller-supplied
       // embedding skips the trunk, i.e. most of the stream) keeps the per-wave stream
-      if (a.mode != RSN_MODE_EMB && a.L.r_stream != 0 && a.num_layers <= RING_MAX_LAYERS && !per_wave_stream)
-        hipLaunchKernelGGL(rsn_field_bf16_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+      if (a.mode != RSN_MODE_EMB && a.L.r_stream != 0 && a.num_layers <= RING_MAX_LAYERS && !per_wave_stream &&
+          (long long)a.n_rays * a.S < (1LL << 31)) {
+        static const int stagger = getenv("RSN_RING_STAGGER") ? atoi(getenv("RSN_RING_STAGGER")) : 0;
+        static const int nw = getenv("RSN_RING_WAVES") ? atoi(getenv("RSN_RING_WAVES")) : 8;
+        FieldArgs b = a;
+        b.stagger = stagger;  // start skew between the workgroups of an XCD, x ~1K cycles x index (tools/ring_sweep.sh)
+        const long long n_points = (long long)a.n_rays * a.S;
+        if (nw == 4) {
+          hipLaunchKernelGGL(rsn_field_bf16_ring_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, b);
+        } else {  // one 8-wave workgroup per CU, 256-point tiles
+          const long long t8 = (n_points + 255) / 256;
+          const long long g8 = t8 < (grid + 1) / 2 ? t8 : (grid + 1) / 2;
+          hipLaunchKernelGGL(rsn_field_bf16_ring_kernel<8>, dim3((unsigned)g8), dim3(512), 0, st, b);
+        }
+      }
       else
         hipLaunchKernelGGL((rsn_field_bf16_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, a);
       break;

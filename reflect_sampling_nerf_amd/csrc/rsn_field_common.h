@@ -27,6 +27,7 @@ struct FieldArgs {
   const float* rough_in;      // RSN_MODE_EMB: optional explicit roughness for the SH attenuation (get_mid's argument)
   rsn_field_saved saved;      // training: activations kept for the backward pass (all NULL in eval)
   long long act_stride;       // floats between consecutive layers in saved.act (= n_points_max * W)
+  int stagger;                // rsn_field_bf16_ring_kernel: start delay of the second workgroup per CU (x s_sleep 127)
 };
 
 // Conical frustum -> Gaussian (nerfstudio conical_frustum_to_gaussian / compute_3d_gaussian, N3),

@@ -17,15 +17,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// sin / cos of an fp32 argument up to ~1e6 (the IPE reaches 2*pi*2*2^16 = 8.2e5), <= 1.5 ulp -- the same quality as
-// ocml's sinf (1.57 ulp measured over the same range), at ~1/4 of its instruction count: instead of the branchy
-// Payne-Hanek path the argument is reduced by multiples of pi/2 in fp64 (two FMAs: fp64 has 29 spare bits for the
-// <= 2^20 quotient) and a degree-7/8 minimax pair is evaluated on [-pi/4, pi/4].  quad = 0: sin, quad = 1: cos.
+// sin / cos of an fp32 argument up to ~1e6 (the IPE reaches 2*pi*2*2^16 = 8.2e5), <= 1.7 ulp -- the quality of ocml's
+// sinf (1.57 ulp measured over the same range) at ~1/5 of its instruction count.  Instead of the branchy Payne-Hanek
+// path the argument is reduced by multiples of pi/2 with a three-constant Cody-Waite scheme on FUSED multiply-adds:
+// pi/2 = C1 + C2 + C3 with C1 = fl32(pi/2); q <= 2^20 is an integer and C1 a multiple of 2^-23, so a - q*C1 is a
+// multiple of 2^-23 below 1 in magnitude and the first fma is EXACT; the second rounds once (2^-25), the third term is
+// 1e-9.  Reduced argument within 3.1e-8 of the true one (measured over 4e6 arguments up to 8.3e5: max |r| 0.87 --
+// the fp32 product a*(2/pi) may pick the neighbouring quadrant, which costs nothing -- and 9.8e-8 / 1.65 ulp on the
+// result).  A degree-7/8 minimax pair is evaluated on the reduced argument.  quad = 0: sin, quad = 1: cos.
+// Round 1 reduced in fp64 (two v_fma_f64 + five conversions per evaluation): same accuracy, ~2x the issue cycles.
 __device__ __forceinline__ float sincos_big(float a, int quad) {
-  const double ad = (double)a;
-  const double q = rint(ad * 0.63661977236758134308);
-  const double rd = fma(-q, 1.57079632679489655800, ad);
-  const float r = (float)fma(-q, 6.12323399573676603587e-17, rd);
+  const float q = rintf(a * 0.63661977236758134308f);
+  float r = __builtin_fmaf(-q, 1.5707963705062866f, a);
+  r = __builtin_fmaf(-q, -4.371138828673793e-08f, r);
+  r = __builtin_fmaf(-q, -1.7151245100058819e-15f, r);
   const int n = (int)q + quad;
   const float s = r * r;
   const float ps = r + r * s * (-1.6666654611e-1f + s * (8.3321608736e-3f + s * (-1.9515295891e-4f)));
