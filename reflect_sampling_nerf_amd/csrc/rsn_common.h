@@ -68,6 +68,8 @@ struct RsnPackedLayout {
   int r_groups;                       // 8-fragment groups per pass over the network
   size_t total;                       // floats
 };
+#ifndef RSN_RING_GROUP_FRAGS
 #define RSN_RING_GROUP_FRAGS 8
+#endif
 
 int rsn_compute_layout(const rsn_field_desc* desc, RsnPackedLayout* L);

@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_kernel(const FieldArgs 
 //   * two workgroups per CU (78 KiB LDS, <= 256 VGPRs): while one encodes or drains accumulators the other's
 //     MFMAs keep the matrix pipe busy.
 // ================================================================================================
+#define RING_ENC_KS ((RSN_ENC_K16 * 8 + RSN_RING_GROUP_FRAGS - 1) / RSN_RING_GROUP_FRAGS * RSN_RING_GROUP_FRAGS / 8)  // enc K-steps incl. padding
+#define RING_RGB_KS (RSN_RING_GROUP_FRAGS == 16 ? 16 : 8)
 #define RING_FIFO 4   // fragments read from the ring ahead of their MFMA (registers: 4 x 4 VGPRs)
 #define RING_GROUP_BYTES (RSN_RING_GROUP_FRAGS * 1024)
 #define RING_STASH_BYTES (RSN_ENC_K16 * 1024)          // per wave: encoded inputs as bf16, [k16][lane][8]
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_kernel(const FieldArgs 
 // waves per SIMD share ONE stream (half the LDS-DMA pieces per MFMA, half the L2 traffic), 8-slot ring (130 KiB).
 template <int NW>
 struct RingCfg {
-  static constexpr int SLOTS = NW == 8 ? 8 : 5;
+  static constexpr int SLOTS = RSN_RING_GROUP_FRAGS == 16 ? 4 : (NW == 8 ? 8 : 5);
   static constexpr int LEAD = SLOTS - 1;              // groups in flight ahead of the group being consumed
   static constexpr int PPW = RSN_RING_GROUP_FRAGS / NW;  // LDS-DMA pieces per wave and group
   static constexpr int RING_BYTES = SLOTS * RING_GROUP_BYTES;
@@ -611,16 +613,20 @@ __global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const F
       init_acc_lds<NB>(acc, bias, h);
 #pragma unroll
       for (int kk = 0; kk < RSN_ENC_K16; ++kk) X[kk] = ST[kk * 64];
-      gemm_ring<NW, NB, RSN_ENC_K16, 16>(acc, X, r, Wf, smem);
+#pragma unroll
+      for (int kk = RSN_ENC_K16; kk < RING_ENC_KS; ++kk) X[kk] = bf16x8{};  // padding K-steps (zero weights): finite operands
+      gemm_ring<NW, NB, RING_ENC_KS, 16>(acc, X, r, Wf, smem);
 #pragma unroll 1
       for (int l = 1; l < a.num_layers; ++l) {
         acc_to_x<NB, NB, true, 16>(acc, X, bias + l * 256, h);
         gemm_ring<NW, NB, 16, 16>(acc, X, r, Wf, smem);
         if (l == a.skip_layer) {
-          bf16x8 XE[RSN_ENC_K16];
+          bf16x8 XE[RING_ENC_KS];
 #pragma unroll
           for (int kk = 0; kk < RSN_ENC_K16; ++kk) XE[kk] = ST[kk * 64];
-          gemm_ring<NW, NB, RSN_ENC_K16, RSN_ENC_K16>(acc, XE, r, Wf, smem);
+#pragma unroll
+          for (int kk = RSN_ENC_K16; kk < RING_ENC_KS; ++kk) XE[kk] = bf16x8{};
+          gemm_ring<NW, NB, RING_ENC_KS, RING_ENC_KS>(acc, XE, r, Wf, smem);
         }
       }
       acc_to_x<NB, NB, true, 16>(acc, X);  // out_activation = ReLU: the embedding
@@ -714,11 +720,13 @@ __global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const F
       gemm_ring<NW, 4, 4, 4>(accm, XS, r, Wf, smem);
       gemm_ring<NW, 4, 16, 16>(accm, X, r, Wf, smem);
       acc_to_x<4, 4, true, 16>(accm, X);  // hidden (128): K=16 steps 0..7
+#pragma unroll
+      for (int kk = 8; kk < RING_RGB_KS; ++kk) X[kk] = bf16x8{};  // padding K-steps of the RGB head
     }
     {
       f32x16 accr[1];
       init_acc_lds<1>(accr, b_rgb, h);
-      gemm_ring<NW, 1, 8, 16>(accr, X, r, Wf, smem);
+      gemm_ring<NW, 1, RING_RGB_KS, 16>(accr, X, r, Wf, smem);
       if (h == 1 && valid && a.out.color) {
         const float m0 = sigmoid_f(accr[0][0]);
         const float m1 = sigmoid_f(accr[0][1]);
@@ -751,9 +759,8 @@ int rsn_launch_field_bf16(int width, long long grid, hipStream_t st, const Field
         FieldArgs b = a;
         b.stagger = stagger;  // start skew between the workgroups of an XCD, x ~1K cycles x index (tools/ring_sweep.sh)
         const long long n_points = (long long)a.n_rays * a.S;
-        if (nw == 4) {
-          hipLaunchKernelGGL(rsn_field_bf16_ring_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, b);
-        } else {  // one 8-wave workgroup per CU, 256-point tiles
+        (void)nw;
+        {  // one 8-wave workgroup per CU, 256-point tiles
           const long long t8 = (n_points + 255) / 256;
           const long long g8 = t8 < (grid + 1) / 2 ? t8 : (grid + 1) / 2;
           hipLaunchKernelGGL(rsn_field_bf16_ring_kernel<8>, dim3((unsigned)g8), dim3(512), 0, st, b);

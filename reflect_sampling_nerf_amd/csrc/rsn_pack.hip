@@ -130,7 +130,9 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   if (d->mma_mode == RSN_MMA_BF16 && d->width == 256) {
     // enc0 7 K-steps x 8 blocks; x layers 16 x 8; enc_skip 7 x 8; heads 16 x 1; bottleneck 16 x 8; mlp_mid SH part
     // 3 (padded to 4) x 4; mlp_mid x part 16 x 4; rgb 8 x 1 -- every GEMM a whole number of 8-fragment groups
-    L->r_groups = RSN_ENC_K16 + (d->num_layers - 1) * 16 + (d->skip_layer >= 1 ? RSN_ENC_K16 : 0) + 2 + 16 + 2 + 8 + 1;
+    const int G = RSN_RING_GROUP_FRAGS;
+    const int enc_ks = (RSN_ENC_K16 * 8 + G - 1) / G * G / 8, rgb_ks = (8 + G - 1) / G * G;
+    L->r_groups = (enc_ks * 8 * (d->skip_layer >= 1 ? 2 : 1) + (d->num_layers - 1) * 128 + 16 + 128 + 16 + 64 + rgb_ks) / G;
     L->r_stream = off;
     off += (size_t)L->r_groups * RSN_RING_GROUP_FRAGS * blk;
   }
@@ -513,16 +515,18 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       q.ks_real = (short)ks_real; q.ks = (short)ks; q.frag0 = frag;
       frag += ks * nbo;
     };
-    piece(L.h_enc0, NB, 0, NB, RSN_ENC_K16, RSN_ENC_K16);
+    const int G = RSN_RING_GROUP_FRAGS;
+    const int enc_ks = (RSN_ENC_K16 * 8 + G - 1) / G * G / 8, rgb_ks = (8 + G - 1) / G * G;  // padded to whole groups
+    piece(L.h_enc0, NB, 0, NB, RSN_ENC_K16, enc_ks);
     for (int l = 1; l < d->num_layers; ++l) {
       piece(L.h_x[l], NB, 0, NB, NB * 2, NB * 2);
-      if (l == d->skip_layer) piece(L.h_enc_skip, NB, 0, NB, RSN_ENC_K16, RSN_ENC_K16);
+      if (l == d->skip_layer) piece(L.h_enc_skip, NB, 0, NB, RSN_ENC_K16, enc_ks);
     }
     piece(L.h_bh, NB + 1, NB, 1, NB * 2, NB * 2);  // heads block first (its epilogue feeds the SH encoding)
     piece(L.h_bh, NB + 1, 0, NB, NB * 2, NB * 2);  // bottleneck
     piece(L.h_mid_sh, NBM, 0, NBM, RSN_SH_K16, 4);
     piece(L.h_mid_x, NBM, 0, NBM, NB * 2, NB * 2);
-    piece(L.h_rgb, 1, 0, 1, NBM * 2, NBM * 2);
+    piece(L.h_rgb, 1, 0, 1, NBM * 2, rgb_ks);
     RSN_REQUIRE(rj.n_pieces <= RING_MAX_PIECES && frag == L.r_groups * RSN_RING_GROUP_FRAGS, RSN_ERR_INVALID_ARGUMENT,
                 "ring stream: %d fragments in %d pieces, layout says %d groups", frag, rj.n_pieces, L.r_groups);
     rj.n_frags = frag;
