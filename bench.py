@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--mma", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="matrix-core arithmetic of the field kernels: f32 = exact fp32 MFMA (default); bf16x6 = fp32 "
                          "emulation by 3-way bf16 splits (fp32-equivalent); bf16x3 / bf16 = reduced precision (eval)")
+    ap.add_argument("--ray-chunk", type=int, default=0,
+                    help="train: walk the batch in chunks of this many rays (gradient accumulation, exact; bounds the "
+                         "activation memory). 0 = the whole batch at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (eval_level, configs[2])")
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays of the bounded CPU-baseline sample (0 = auto)")
@@ -239,7 +242,7 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
     state = {"it": 100, "M": 0, "loss": None}  # past the 50-step loss warm-up: all eight loss terms are live
 
     def step(_i=None):
-        state["loss"] = train_step(model, rb, batch, optimizer, reducer, state["it"])
+        state["loss"] = train_step(model, rb, batch, optimizer, reducer, state["it"], ray_chunk=args.ray_chunk or None)
         state["it"] += 1
         state["M"] += int(getattr(model, "_last_num_reflected", 0))
         dog.beat()
@@ -248,6 +251,7 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
         step()
     state["M"] = 0
     timer = ops.KernelTimer() if time_kernels else None
+    torch.cuda.reset_peak_memory_stats()
     ops.TIMER = timer
     try:
         elapsed = timed_region(dist, share, dev, steps, step)
@@ -257,7 +261,8 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
     rec = {"value": world * R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
            "warmup": warmup, "n_gpus": world, "loss": float(state["loss"]),
            "reflect_ray_fraction": state["M"] / float(steps * R), "host_syncs_in_reducer":
-               (reducer.host_syncs if reducer is not None else 0)}
+               (reducer.host_syncs if reducer is not None else 0),
+           "peak_device_memory_gb": torch.cuda.max_memory_allocated() / 2**30, "ray_chunk": args.ray_chunk or None}
     if timer is not None:
         tot = timer.totals()
         pts = lambda k: tot.get(k, {"work": {}})["work"].get("points", 0)  # noqa: E731
@@ -460,14 +465,21 @@ def main():
                     "train_step": {k: rec[k] for k in ("algorithmic_flop_per_step", "flop_formula", "kernels",
                                                        "end_to_end_tflops", "end_to_end_frac_of_fp32_mfma_peak",
                                                        "other_ms_per_step", "loss", "reflect_ray_fraction",
-                                                       "host_syncs_in_reducer")},
+                                                       "host_syncs_in_reducer", "peak_device_memory_gb", "ray_chunk")},
                 }
             if world == 1 and not args.no_secondary and args.mma == "f32":
                 # secondary legs (untimed for the headline): configs[1] eval level and the configs[2] training shape
                 lv = run_level(pkg, args, dev, args.steps, args.warmup, dog)
                 c2 = run_train(pkg, args, dev, rank, world, None, share, (64, 128, 64, 64), min(args.steps, 10),
                                min(max(args.warmup, 1), 3), dog, time_kernels=False)
+                x6_args = argparse.Namespace(**{**vars(args), "mma": "bf16x6"})
+                x6 = run_train(pkg, x6_args, dev, rank, world, None, share, samples, min(args.steps, 10),
+                               min(max(args.warmup, 1), 3), dog, time_kernels=False)
                 line["eval_level"] = lv
+                line["train_step_bf16x6_sweeps"] = {
+                    "workload": "the headline step with the forward / backward sweeps on split-bf16 MFMA (3-way split, 6 "
+                                "products, fp32 accumulate: fp32-equivalent, opt-in); weight gradients stay exact fp32",
+                    **{k: x6[k] for k in ("value", "unit", "ms_per_step", "steps")}}
                 line["train_step_configs2"] = {
                     "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect 64 + 64, forward + backward "
                                 "(+ loss + RAdam)" % R,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 10
+#define RSN_ABI_VERSION 11
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -122,6 +122,16 @@ const char* rsn_last_error(void);
 size_t rsn_packed_weights_bytes(const rsn_field_desc* desc);
 int rsn_pack_weights(const rsn_field_desc* desc, const rsn_field_params* params, float* packed,
                      size_t packed_bytes, void* stream);
+
+/* The same result in ONE kernel launch per call (plus one for the split-bf16 copies and one for the bf16 ring stream
+ * when desc->mma_mode asks for them) instead of one launch per segment: the per-segment job descriptors are kept in a
+ * caller-owned device buffer `table` of rsn_pack_table_bytes() bytes.  They depend only on desc and on the parameter /
+ * packed POINTERS: pass rebuild_table != 0 on the first call and whenever one of those changed (one asynchronous
+ * host-to-device copy on `stream`), 0 otherwise (the optimiser step of a training loop: values change, pointers do
+ * not). */
+size_t rsn_pack_table_bytes(void);
+int rsn_pack_weights_table(const rsn_field_desc* desc, const rsn_field_params* params, float* packed,
+                           size_t packed_bytes, void* table, size_t table_bytes, int32_t rebuild_table, void* stream);
 
 /* ---- samplers --------------------------------------------------------------------------------
  * rsn_sample_spaced replaces UniformSampler / ReciprocalSampler.generate_ray_samples
@@ -367,8 +377,10 @@ typedef struct rsn_reflect_io {
   float* fars2;               /* [R]   reflect_far */
   float* reflect_coarse;      /* [R,3] white*(1-acc) */
   float* reflect_fine;        /* [R,3] white*(1-acc) */
+  int32_t* workspace;         /* rsn_reflect_workspace_bytes(R) bytes, contents irrelevant (per-block counts) */
 } rsn_reflect_io;
 
+size_t rsn_reflect_workspace_bytes(int32_t n_rays);
 int rsn_reflect_setup(int32_t n_rays, float reflect_far, const rsn_reflect_io* io, void* stream);
 
 /* rsn_reflect_combine: out[ray_index[i]] = clip(diff[ray_index[i]] + tint[ray_index[i]] * comp[i], 0, 1)
@@ -395,6 +407,12 @@ int rsn_loss_forward_backward(int32_t n_rays, int32_t s_coarse, int32_t s_fine, 
                               const float* const* pred_normals2, const float* const* n_dot_d2, const float* coef8,
                               float* losses8, float* const* g_rgb4, float* const* g_pred_normals2,
                               float* const* g_n_dot_d2, void* stream);
+
+/* Chain rule for the gradients rsn_loss_forward_backward wrote: g_rgb4[k] *= upstream8[k], g_pred_normals2[lv] *=
+ * upstream8[4 + lv], g_n_dot_d2[lv] *= upstream8[6 + lv], in place, upstream8 = d total / d (scaled loss k) in DEVICE
+ * memory (what autograd hands to the backward of get_loss_dict's terms; all ones for loss = sum of the terms). */
+int rsn_loss_scale_grads(int32_t n_rays, int32_t s_coarse, int32_t s_fine, const float* upstream8, float* const* g_rgb4,
+                         float* const* g_pred_normals2, float* const* g_n_dot_d2, void* stream);
 
 /* rsn_radam_step: one RAdam update (torch.optim.RAdam semantics; the reference's optimiser for the "fields" group,
  * reflect_sampling_nerf_config.py:50-53: lr 1e-3, eps 1e-15, betas 0.9/0.999) over all parameter tensors in one

@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 10
+RSN_ABI_VERSION = 11
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -80,7 +80,7 @@ class ReflectIO(C.Structure):
     _fields_ = [(n, _fp) for n in
                 ("origins", "directions", "accumulation", "depth", "pred_normals", "roughness", "mask", "n_masked",
                  "ray_index", "n_dot_d", "origins2", "directions2", "sqradius", "pixel_area2", "nears2", "fars2",
-                 "reflect_coarse", "reflect_fine")]
+                 "reflect_coarse", "reflect_fine", "workspace")]
 
 
 _SIGNATURES = {
@@ -88,6 +88,9 @@ _SIGNATURES = {
     "rsn_last_error": (C.c_char_p, []),
     "rsn_packed_weights_bytes": (C.c_size_t, [C.POINTER(FieldDesc)]),
     "rsn_pack_weights": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), _fp, C.c_size_t, C.c_void_p]),
+    "rsn_pack_table_bytes": (C.c_size_t, []),
+    "rsn_pack_weights_table": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), _fp, C.c_size_t, _fp, C.c_size_t,
+                                         C.c_int32, C.c_void_p]),
     "rsn_sample_spaced": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_float, _fp, _fp, _fp, _fp, _fp,
                                     C.c_void_p]),
     "rsn_sample_pdf": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _fp, _fp,
@@ -117,6 +120,8 @@ _SIGNATURES = {
     "rsn_loss_forward_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp),
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_float), _fp,
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.c_void_p]),
+    "rsn_loss_scale_grads": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp),
+                                       C.c_void_p]),
     "rsn_radam_step": (C.c_int, [C.c_int32, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp),
                                  C.POINTER(C.c_int32), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
@@ -135,6 +140,7 @@ _SIGNATURES = {
                                               C.POINTER(FieldOutputs), _fp, C.c_void_p]),
     "rsn_composite": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CompositeIO),
                                 C.c_void_p]),
+    "rsn_reflect_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "rsn_reflect_setup": (C.c_int, [C.c_int32, C.c_float, C.POINTER(ReflectIO), C.c_void_p]),
     "rsn_reflect_combine": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
 }

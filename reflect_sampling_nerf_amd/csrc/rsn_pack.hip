@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "rsn_common.h"
 
@@ -159,10 +160,10 @@ struct PackJob {
   int16_t row_src[PACK_MAX_ROWS];  // which src a packed row comes from, -1 = zero row
   int16_t row_idx[PACK_MAX_ROWS];  // row inside that src
   int16_t col[PACK_MAX_COLS];      // source column of packed k, -1 = zero
+  int16_t col_src[PACK_MAX_COLS];  // transpose == 3: which src packed k comes from (its row col[k]), -1 = zero
 };
 
-__global__ void rsn_pack_kernel(const PackJob job) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_elem(const PackJob& job, int e) {
   if (job.is_bias) {
     if (e < job.n_rows) {
       const int rs = job.row_src[e];
@@ -182,8 +183,10 @@ __global__ void rsn_pack_kernel(const PackJob job) {
   const int rs = job.row_src[n];
   const int c = job.col[k];
   float v = 0.0f;
-  if (job.transpose == 2) {  // overlay: write only live (row, k) pairs of a transposed source
-    if (rs >= 0 && c >= 0) job.dst[e] = job.src[rs][(size_t)c * job.ld[rs] + job.row_idx[n]];
+  if (job.transpose == 3) {  // transposed, the SOURCE tensor selected by k ([heads]^T: one small tensor per head)
+    const int cs = job.col_src[k];
+    if (rs >= 0 && c >= 0 && cs >= 0) v = job.src[cs][(size_t)c * job.ld[cs] + job.row_idx[n]];
+    job.dst[e] = v;
     return;
   }
   if (rs >= 0 && c >= 0)
@@ -192,12 +195,37 @@ __global__ void rsn_pack_kernel(const PackJob job) {
   job.dst[e] = v;
 }
 
+__global__ void rsn_pack_kernel(const PackJob job) { pack_elem(job, blockIdx.x * blockDim.x + threadIdx.x); }
+
+// Every segment in ONE launch (rsn_pack_weights_table): the job descriptors live in device memory, uploaded once per
+// (parameter pointers, shape); workgroup b serves job j with block_start[j] <= b < block_start[j + 1].
+#define PACK_MAX_JOBS 64
+struct PackTable {
+  int n_jobs, n_blocks;
+  int block_start[PACK_MAX_JOBS + 1];
+  PackJob jobs[PACK_MAX_JOBS];
+};
+
+__global__ void rsn_pack_all_kernel(const PackTable* __restrict__ t) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = t->n_jobs - 1;
+  while (lo < hi) {  // last job whose first block is <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (t->block_start[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  pack_elem(t->jobs[lo], (b - t->block_start[lo]) * 256 + (int)threadIdx.x);
+}
+
+// all split-bf16 copies in one launch
+#define SPLIT_MAX_SEGS 48
+struct SplitSeg { unsigned src, dst; short n_it, nbo; int block0; };
+struct SplitJob { float* packed; int n_segs; SplitSeg s[SPLIT_MAX_SEGS]; };
+
 // split-bf16 copy of an already packed fp32 segment [it][nb][lane][4] -> [k16][nb][split(3)][lane][8 bf16]:
 // element e of K=16 step kk is the fp32 value of K-iteration 2kk + (e>>2), component e&3 (zero beyond n_it), split
 // EXACTLY into three bf16 (v = b1 + b2 + b3 up to 2^-24): the K=16 MFMA step consumes the same lane-local
 // activations as the two fp32 K-iterations it replaces.  Works for forward and transposed segments alike.
-__global__ void rsn_pack_split_kernel(const float* __restrict__ src, int n_it, int nbo, float* dstf) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void split_elem(const float* __restrict__ src, int n_it, int nbo, float* dstf, int e) {
   const int n_k16 = (n_it + 1) / 2;
   if (e >= n_k16 * nbo * 512) return;
   const int ee = e & 7;
@@ -218,6 +246,17 @@ __global__ void rsn_pack_split_kernel(const float* __restrict__ src, int n_it, i
   dst[((base + 0) * 64 + lane) * 8 + ee] = b1;
   dst[((base + 1) * 64 + lane) * 8 + ee] = b2;
   dst[((base + 2) * 64 + lane) * 8 + ee] = b3;
+}
+
+__global__ void rsn_pack_split_kernel(const float* __restrict__ src, int n_it, int nbo, float* dstf) {
+  split_elem(src, n_it, nbo, dstf, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ void rsn_pack_split_all_kernel(const SplitJob job) {
+  int si = 0;
+  while (si + 1 < job.n_segs && job.s[si + 1].block0 <= (int)blockIdx.x) ++si;
+  const SplitSeg sg = job.s[si];
+  split_elem(job.packed + sg.src, sg.n_it, sg.nbo, job.packed + sg.dst, ((int)blockIdx.x - sg.block0) * 256 + (int)threadIdx.x);
 }
 
 // ---- ring stream (RSN_MMA_BF16, width 256): split-0 fragments of the h_* segments re-ordered into consumption order
@@ -301,7 +340,24 @@ void cols_sh(PackJob& j) {
   }
 }
 
+// rsn_pack_weights_table collects the jobs instead of launching them one by one
+struct PackCollector {
+  float* packed;
+  std::vector<PackJob> jobs;
+  std::vector<SplitSeg> splits;
+  bool have_ring = false;
+  RingJob ring;
+};
+thread_local PackCollector* g_collect = nullptr;
+
 int split_seg(const float* src, int n_it, int nbo, float* dst, hipStream_t st) {
+  if (g_collect) {
+    SplitSeg sg;
+    sg.src = (unsigned)(src - g_collect->packed); sg.dst = (unsigned)(dst - g_collect->packed);
+    sg.n_it = (short)n_it; sg.nbo = (short)nbo; sg.block0 = 0;
+    g_collect->splits.push_back(sg);
+    return RSN_OK;
+  }
   const int total = ((n_it + 1) / 2) * nbo * 512;
   const int threads = 256;
   hipLaunchKernelGGL(rsn_pack_split_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, src, n_it, nbo,
@@ -311,6 +367,10 @@ int split_seg(const float* src, int n_it, int nbo, float* dst, hipStream_t st) {
 }
 
 int launch(const PackJob& j, hipStream_t st) {
+  if (g_collect) {
+    g_collect->jobs.push_back(j);
+    return RSN_OK;
+  }
   const int total = j.is_bias ? j.n_rows : j.n_it * j.nbo * 256;
   const int threads = 256;
   hipLaunchKernelGGL(rsn_pack_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, j);
@@ -322,6 +382,7 @@ void clear_job(PackJob& j) {
   memset(&j, 0, sizeof(j));
   for (int i = 0; i < PACK_MAX_ROWS; ++i) j.row_src[i] = -1;
   for (int i = 0; i < PACK_MAX_COLS; ++i) j.col[i] = -1;
+  for (int i = 0; i < PACK_MAX_COLS; ++i) j.col_src[i] = -1;
 }
 
 }  // namespace
@@ -450,24 +511,18 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     j.transpose = 1; j.src[0] = p->bottleneck_w; j.ld[0] = W; j.dst = packed + L.wT_bh; j.n_it = NB * 4; j.nbo = NB;
     rows_natural(j, W); cols_natural(j, W, 0);
     if ((rc = launch(j, st)) != RSN_OK) return rc;
-    // heads part: 4 K-iterations (k = 0..31 -> heads rows), one job per head tensor
+    // heads part: 4 K-iterations (k = 0..31 -> heads rows); the source tensor depends on k (one small tensor per head)
     const float* hw[5] = {p->density_w, p->normals_w, p->diff_w, p->roughness_w, p->tint_w};
     const int hbase[5] = {0, 1, 4, 8, 12};
     const int hrows[5] = {1, 3, 3, 1, 3};
-    // zero-fill then overlay: first a zero job
     clear_job(j);
-    j.transpose = 1; j.src[0] = p->density_w; j.ld[0] = W; j.dst = packed + L.wT_bh + (size_t)(NB * 4) * NB * 256;
-    j.n_it = 4; j.nbo = NB;
-    rows_natural(j, W);  // all cols -1 -> zeros
+    j.transpose = 3;
+    for (int t = 0; t < 5; ++t) { j.src[t] = hw[t]; j.ld[t] = W; }
+    j.dst = packed + L.wT_bh + (size_t)(NB * 4) * NB * 256; j.n_it = 4; j.nbo = NB;
+    rows_natural(j, W);
+    for (int t = 0; t < 5; ++t)
+      for (int c = 0; c < hrows[t]; ++c) { j.col[hbase[t] + c] = (int16_t)c; j.col_src[hbase[t] + c] = (int16_t)t; }
     if ((rc = launch(j, st)) != RSN_OK) return rc;
-    for (int t = 0; t < 5; ++t) {
-      clear_job(j);
-      j.transpose = 2;  // overlay: only write elements whose k is live
-      j.src[0] = hw[t]; j.ld[0] = W; j.dst = packed + L.wT_bh + (size_t)(NB * 4) * NB * 256; j.n_it = 4; j.nbo = NB;
-      rows_natural(j, W);
-      for (int c = 0; c < hrows[t]; ++c) j.col[hbase[t] + c] = (int16_t)c;
-      if ((rc = launch(j, st)) != RSN_OK) return rc;
-    }
   }
   clear_job(j);  // (mlp_mid bottleneck part)^T: rows = W (source columns 34..34+W), K = mid rows
   j.transpose = 1; j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; j.dst = packed + L.wT_mid_x; j.n_it = NBM * 4; j.nbo = NB;
@@ -530,7 +585,73 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     RSN_REQUIRE(rj.n_pieces <= RING_MAX_PIECES && frag == L.r_groups * RSN_RING_GROUP_FRAGS, RSN_ERR_INVALID_ARGUMENT,
                 "ring stream: %d fragments in %d pieces, layout says %d groups", frag, rj.n_pieces, L.r_groups);
     rj.n_frags = frag;
-    hipLaunchKernelGGL(rsn_pack_ring_kernel, dim3((unsigned)frag), dim3(64), 0, st, rj);
+    if (g_collect) {
+      g_collect->have_ring = true;
+      g_collect->ring = rj;
+    } else {
+      hipLaunchKernelGGL(rsn_pack_ring_kernel, dim3((unsigned)frag), dim3(64), 0, st, rj);
+      RSN_HIP(hipGetLastError());
+    }
+  }
+  return RSN_OK;
+}
+
+// ---- the same in (at most) three launches: every fp32 segment, every split-bf16 copy, the ring stream ----------------
+extern "C" size_t rsn_pack_table_bytes(void) { return sizeof(PackTable); }
+
+extern "C" int rsn_pack_weights_table(const rsn_field_desc* d, const rsn_field_params* p, float* packed,
+                                      size_t packed_bytes, void* table, size_t table_bytes, int32_t rebuild_table,
+                                      void* stream) {
+  RSN_REQUIRE(table != nullptr && table_bytes >= sizeof(PackTable), RSN_ERR_WORKSPACE,
+              "job table buffer too small: %zu < %zu bytes", table_bytes, sizeof(PackTable));
+  hipStream_t st = (hipStream_t)stream;
+  // the descriptors depend on the shape and on the parameter / packed POINTERS only: collected on the host, laid out
+  // as one table and (when the caller says the pointers changed, or on first use) uploaded once
+  static thread_local PackCollector col;
+  col.packed = packed;
+  col.jobs.clear();
+  col.splits.clear();
+  col.have_ring = false;
+  g_collect = &col;
+  const int rc = rsn_pack_weights(d, p, packed, packed_bytes, stream);
+  g_collect = nullptr;
+  if (rc != RSN_OK) return rc;
+  RSN_REQUIRE((int)col.jobs.size() <= PACK_MAX_JOBS && (int)col.splits.size() <= SPLIT_MAX_SEGS, RSN_ERR_UNSUPPORTED,
+              "%zu pack jobs / %zu split segments exceed the table", col.jobs.size(), col.splits.size());
+  int blocks = 0;
+  static thread_local PackTable host_table;  // stays alive behind the asynchronous upload
+  if (rebuild_table) {
+    host_table.n_jobs = (int)col.jobs.size();
+    for (int i = 0; i < host_table.n_jobs; ++i) {
+      const PackJob& j = col.jobs[i];
+      host_table.block_start[i] = blocks;
+      host_table.jobs[i] = j;
+      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * 256) + 255) / 256;
+    }
+    host_table.block_start[host_table.n_jobs] = blocks;
+    host_table.n_blocks = blocks;
+    RSN_HIP(hipMemcpyAsync(table, &host_table, sizeof(PackTable), hipMemcpyHostToDevice, st));
+  } else {
+    for (const PackJob& j : col.jobs) blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * 256) + 255) / 256;
+  }
+  hipLaunchKernelGGL(rsn_pack_all_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const PackTable*)table);
+  RSN_HIP(hipGetLastError());
+  if (!col.splits.empty()) {
+    SplitJob sj;
+    memset(&sj, 0, sizeof(sj));
+    sj.packed = packed;
+    sj.n_segs = (int)col.splits.size();
+    int b = 0;
+    for (int i = 0; i < sj.n_segs; ++i) {
+      sj.s[i] = col.splits[i];
+      sj.s[i].block0 = b;
+      b += (((sj.s[i].n_it + 1) / 2) * sj.s[i].nbo * 512 + 255) / 256;
+    }
+    hipLaunchKernelGGL(rsn_pack_split_all_kernel, dim3((unsigned)b), dim3(256), 0, st, sj);
+    RSN_HIP(hipGetLastError());
+  }
+  if (col.have_ring) {
+    hipLaunchKernelGGL(rsn_pack_ring_kernel, dim3((unsigned)col.ring.n_frags), dim3(64), 0, st, col.ring);
     RSN_HIP(hipGetLastError());
   }
   return RSN_OK;

@@ -523,65 +523,94 @@ extern "C" int rsn_reflect_backward(int32_t n_rays, const int32_t* n_masked, con
 // A single 1024-thread workgroup walks the rays in order (block scan per 1024-ray chunk) so the
 // compaction is stable like the reference's boolean-mask gather.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rsn_reflect_setup_kernel(int R, float reflect_far, const rsn_reflect_io io) {
+// Two passes over 1024-ray blocks, any number of workgroups (round 1 ran ONE workgroup over all rays):
+//   count   : mask, n.d, the default reflect colours; workspace[b] = masked rays of block b;
+//   scatter : base_b = sum of workspace[0..b) (every block sums for itself: <= R/1024 integers), then the stable
+//             in-block compaction by wave ballots; the last block publishes M.
+#define RSN_REFLECT_BLOCK 1024
+__global__ __launch_bounds__(RSN_REFLECT_BLOCK) void rsn_reflect_count_kernel(int R, const rsn_reflect_io io) {
   __shared__ int s_wave_tot[16];
-  __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int start = 0; start < R; start += 1024) {
-    const int r = start + tid;
-    bool mk = false;
-    float ndd = 0.0f, accv = 0.0f;
-    float d[3] = {0, 0, 0}, n[3] = {0, 0, 0};
-    if (r < R) {
+  const int r = blockIdx.x * RSN_REFLECT_BLOCK + tid;
+  bool mk = false;
+  if (r < R) {
+    float d[3], n[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { d[c] = io.directions[r * 3 + c]; n[c] = io.pred_normals[r * 3 + c]; }
-      ndd = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
-      accv = io.accumulation[r];
-      mk = (accv > 1e-2f) && (ndd < 0.0f);
-      io.mask[r] = mk ? 1 : 0;
-      if (io.n_dot_d) io.n_dot_d[r] = ndd;
-      const float dflt = 1.0f * (1.0f - accv);
+    for (int c = 0; c < 3; ++c) { d[c] = io.directions[r * 3 + c]; n[c] = io.pred_normals[r * 3 + c]; }
+    const float ndd = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+    const float accv = io.accumulation[r];
+    mk = (accv > 1e-2f) && (ndd < 0.0f);
+    io.mask[r] = mk ? 1 : 0;
+    if (io.n_dot_d) io.n_dot_d[r] = ndd;
+    const float dflt = 1.0f * (1.0f - accv);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { io.reflect_coarse[r * 3 + c] = dflt; io.reflect_fine[r * 3 + c] = dflt; }
-    }
-    const unsigned long long bal = __ballot(mk);
-    const int in_wave = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave_tot[wid] = __builtin_popcountll(bal);
-    __syncthreads();
-    int wave_off = 0, chunk_tot = 0;
-    for (int wv = 0; wv < 16; ++wv) {
-      const int t = s_wave_tot[wv];
-      if (wv < wid) wave_off += t;
-      chunk_tot += t;
-    }
-    const int base = s_base;
-    if (mk) {
-      const int i = base + wave_off + in_wave;
-      io.ray_index[i] = r;
-      const float dep = io.depth[r];
-      float rf[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        io.origins2[i * 3 + c] = io.origins[r * 3 + c] + dep * d[c];
-        rf[c] = d[c] - 2.0f * ndd * n[c];
-      }
-      const float nrm = fmaxf(sqrtf(rf[0] * rf[0] + rf[1] * rf[1] + rf[2] * rf[2]), 1e-12f);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) io.directions2[i * 3 + c] = rf[c] / nrm;
-      const float rough = io.roughness[r];
-      const float sq = 2.0f * fabsf(ndd) * (rough * rough);
-      io.sqradius[i] = sq;
-      io.pixel_area2[i] = 3.141592653589793f * sq;
-      io.nears2[i] = 0.0f;  // zeros_like(nears) * self.near == 0 (reflect_sampling_nerf_model.py:287)
-      io.fars2[i] = reflect_far;
-    }
-    __syncthreads();
-    if (tid == 0) s_base = base + chunk_tot;
-    __syncthreads();
+    for (int c = 0; c < 3; ++c) { io.reflect_coarse[r * 3 + c] = dflt; io.reflect_fine[r * 3 + c] = dflt; }
   }
-  if (tid == 0) *io.n_masked = s_base;
+  const unsigned long long bal = __ballot(mk);
+  if (lane == 0) s_wave_tot[wid] = __builtin_popcountll(bal);
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+#pragma unroll
+    for (int wv = 0; wv < 16; ++wv) t += s_wave_tot[wv];
+    io.workspace[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(RSN_REFLECT_BLOCK) void rsn_reflect_scatter_kernel(int R, float reflect_far,
+                                                                                const rsn_reflect_io io) {
+  __shared__ int s_wave_tot[16];
+  __shared__ int s_part[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // base of this block: sum of the preceding blocks' counts
+  int part = 0;
+  for (int j = tid; j < (int)blockIdx.x; j += RSN_REFLECT_BLOCK) part += io.workspace[j];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+  if (lane == 0) s_part[wid] = part;
+  const int r = blockIdx.x * RSN_REFLECT_BLOCK + tid;
+  const bool mk = r < R && io.mask[r] != 0;
+  const unsigned long long bal = __ballot(mk);
+  const int in_wave = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave_tot[wid] = __builtin_popcountll(bal);
+  __syncthreads();
+  int base = 0, wave_off = 0, chunk_tot = 0;
+#pragma unroll
+  for (int wv = 0; wv < 16; ++wv) {
+    base += s_part[wv];
+    const int t = s_wave_tot[wv];
+    if (wv < wid) wave_off += t;
+    chunk_tot += t;
+  }
+  if (mk) {
+    float d[3], n[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { d[c] = io.directions[r * 3 + c]; n[c] = io.pred_normals[r * 3 + c]; }
+    const float ndd = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+    const int i = base + wave_off + in_wave;
+    io.ray_index[i] = r;
+    const float dep = io.depth[r];
+    float rf[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      io.origins2[i * 3 + c] = io.origins[r * 3 + c] + dep * d[c];
+      rf[c] = d[c] - 2.0f * ndd * n[c];
+    }
+    const float nrm = fmaxf(sqrtf(rf[0] * rf[0] + rf[1] * rf[1] + rf[2] * rf[2]), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) io.directions2[i * 3 + c] = rf[c] / nrm;
+    const float rough = io.roughness[r];
+    const float sq = 2.0f * fabsf(ndd) * (rough * rough);
+    io.sqradius[i] = sq;
+    io.pixel_area2[i] = 3.141592653589793f * sq;
+    io.nears2[i] = 0.0f;  // zeros_like(nears) * self.near == 0 (reflect_sampling_nerf_model.py:287)
+    io.fars2[i] = reflect_far;
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) *io.n_masked = base + chunk_tot;
+}
+
+extern "C" size_t rsn_reflect_workspace_bytes(int32_t n_rays) {
+  return (size_t)((n_rays > 0 ? n_rays : 0) + RSN_REFLECT_BLOCK - 1) / RSN_REFLECT_BLOCK * sizeof(int32_t) + sizeof(int32_t);
 }
 
 extern "C" int rsn_reflect_setup(int32_t n_rays, float reflect_far, const rsn_reflect_io* io, void* stream) {
@@ -591,9 +620,16 @@ extern "C" int rsn_reflect_setup(int32_t n_rays, float reflect_far, const rsn_re
   RSN_REQUIRE(n_rays == 0 || (io->origins && io->directions && io->accumulation && io->depth && io->pred_normals &&
                               io->roughness && io->mask && io->ray_index && io->origins2 && io->directions2 &&
                               io->sqradius && io->pixel_area2 && io->nears2 && io->fars2 && io->reflect_coarse &&
-                              io->reflect_fine),
+                              io->reflect_fine && io->workspace),
               RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
-  hipLaunchKernelGGL(rsn_reflect_setup_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_rays, reflect_far, *io);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rays == 0) {
+    RSN_HIP(hipMemsetAsync(io->n_masked, 0, sizeof(int32_t), st));
+    return RSN_OK;
+  }
+  const unsigned blocks = (unsigned)((n_rays + RSN_REFLECT_BLOCK - 1) / RSN_REFLECT_BLOCK);
+  hipLaunchKernelGGL(rsn_reflect_count_kernel, dim3(blocks), dim3(RSN_REFLECT_BLOCK), 0, st, n_rays, *io);
+  hipLaunchKernelGGL(rsn_reflect_scatter_kernel, dim3(blocks), dim3(RSN_REFLECT_BLOCK), 0, st, n_rays, reflect_far, *io);
   RSN_HIP(hipGetLastError());
   return RSN_OK;
 }

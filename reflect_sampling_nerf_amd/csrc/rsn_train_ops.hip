@@ -110,6 +110,61 @@ extern "C" int rsn_loss_forward_backward(int32_t n_rays, int32_t s_coarse, int32
   return RSN_OK;
 }
 
+// In-place chain rule for the loss gradients: g_rgb[k] *= up[k] (k = 0..3), g_pn[lv] *= up[4 + lv], g_ndd[lv] *=
+// up[6 + lv] with the eight upstream gradients d total / d loss_k read from DEVICE memory -- one launch instead of a
+// dozen elementwise multiplications in the host framework's autograd.
+struct LossScaleArgs {
+  int R, Sc, Sf;
+  const float* up;
+  float* g_rgb[4];
+  float* g_pn[2];
+  float* g_ndd[2];
+};
+
+__global__ __launch_bounds__(256) void rsn_loss_scale_kernel(const LossScaleArgs a) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float up[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) up[k] = a.up[k];
+  const long long n3 = (long long)a.R * 3;
+  for (long long e = tid; e < n3; e += stride) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (a.g_rgb[k]) a.g_rgb[k][e] *= up[k];
+  }
+#pragma unroll
+  for (int lv = 0; lv < 2; ++lv) {
+    const long long n = (long long)a.R * (lv == 0 ? a.Sc : a.Sf);
+    for (long long e = tid; e < n; e += stride) {
+      if (a.g_pn[lv]) {
+        a.g_pn[lv][e * 3 + 0] *= up[4 + lv];
+        a.g_pn[lv][e * 3 + 1] *= up[4 + lv];
+        a.g_pn[lv][e * 3 + 2] *= up[4 + lv];
+      }
+      if (a.g_ndd[lv]) a.g_ndd[lv][e] *= up[6 + lv];
+    }
+  }
+}
+
+extern "C" int rsn_loss_scale_grads(int32_t n_rays, int32_t s_coarse, int32_t s_fine, const float* upstream8,
+                                    float* const* g_rgb4, float* const* g_pred_normals2, float* const* g_n_dot_d2,
+                                    void* stream) {
+  RSN_REQUIRE(n_rays >= 1 && s_coarse >= 1 && s_fine >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d s=%d,%d", n_rays,
+              s_coarse, s_fine);
+  RSN_REQUIRE(upstream8 && g_rgb4 && g_pred_normals2 && g_n_dot_d2, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  LossScaleArgs a;
+  a.R = n_rays; a.Sc = s_coarse; a.Sf = s_fine; a.up = upstream8;
+  for (int k = 0; k < 4; ++k) a.g_rgb[k] = g_rgb4[k];
+  for (int k = 0; k < 2; ++k) { a.g_pn[k] = g_pred_normals2[k]; a.g_ndd[k] = g_n_dot_d2[k]; }
+  const long long work = (long long)n_rays * (s_coarse > s_fine ? s_coarse : s_fine);
+  long long blocks = (work + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(rsn_loss_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // RAdam, multi-tensor (torch.optim.RAdam: betas, eps, no weight decay, decoupled = false)
 // ---------------------------------------------------------------------------------------------------

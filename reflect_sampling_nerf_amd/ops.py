@@ -128,7 +128,7 @@ def reflect_setup(origins: Tensor, directions: Tensor, accumulation: Tensor, dep
     f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
     out = {
         "mask": torch.empty(R, device=dev, dtype=torch.uint8),
-        "n_masked": torch.zeros(1, device=dev, dtype=torch.int32),
+        "n_masked": torch.empty(1, device=dev, dtype=torch.int32),  # written by the kernel (also when R == 0)
         "ray_index": torch.empty(R, device=dev, dtype=torch.int32),
         "n_dot_d": f(R), "origins2": f(R, 3), "directions2": f(R, 3), "sqradius": f(R), "pixel_area2": f(R),
         "nears2": f(R), "fars2": f(R), "reflect_coarse": f(R, 3), "reflect_fine": f(R, 3),
@@ -138,6 +138,8 @@ def reflect_setup(origins: Tensor, directions: Tensor, accumulation: Tensor, dep
     io.pred_normals, io.roughness = ptr(normals), ptr(roughness)
     for k, v in out.items():
         setattr(io, k, ptr(v))
+    ws = torch.empty(max(1, lib.rsn_reflect_workspace_bytes(R) // 4), device=dev, dtype=torch.int32)
+    io.workspace = ptr(ws)
     check(lib.rsn_reflect_setup(R, reflect_far, io, _stream()))
     return out
 

@@ -133,15 +133,42 @@ def apply_loss_warmup(model, step: int) -> None:
         c["orientation_loss_fine"] = 1e-1
 
 
-def train_step(model, ray_bundle, batch, optimizer, reducer: Optional[FlatGradAllReduce], step: int) -> torch.Tensor:
-    """One optimisation step: warm-up -> forward -> get_loss_dict -> backward -> gradient average -> optimiser."""
+_MEAN_TERMS = ("loss_mid_coarse", "loss_mid_fine", "loss_reflect_mid_coarse", "loss_reflect_mid_fine")
+
+
+def train_step(model, ray_bundle, batch, optimizer, reducer: Optional[FlatGradAllReduce], step: int,
+               ray_chunk: Optional[int] = None) -> torch.Tensor:
+    """One optimisation step: warm-up -> forward -> get_loss_dict -> backward -> gradient average -> optimiser.
+
+    ray_chunk: bound the step's activation memory.  The training forward keeps ~10.4 KB per sample for the backward
+    pass and the backward sweep writes ~9.8 KB per sample of layer gradients for the weight-gradient kernels (DESIGN
+    4.3): ~28 GB at 4096 rays x (128 + 128 + reflect) and proportionally more for larger batches.  With ray_chunk = n
+    the batch is walked in chunks of n rays -- forward, loss, backward per chunk, the parameter gradients ACCUMULATING
+    (autograd adds into .grad; the weight-gradient kernels accumulate anyway) -- so the live activations are those of one
+    chunk whatever the batch size.  The result is the whole-batch step exactly: the four MSE terms are means over the
+    batch (a chunk of m of R rays enters with weight m/R), the normal / orientation terms are sums (model.py:395-407);
+    the gradient all-reduce and the optimiser run once, after the last chunk."""
     apply_loss_warmup(model, step)
     optimizer.zero_grad(set_to_none=True)
-    outputs = model(ray_bundle)
-    loss_dict = model.get_loss_dict(outputs, batch)
-    loss = sum(loss_dict.values())
-    loss.backward()
+    R = ray_bundle.origins.shape[0]
+    if not ray_chunk or ray_chunk >= R:
+        outputs = model(ray_bundle)
+        loss_dict = model.get_loss_dict(outputs, batch)
+        loss = sum(loss_dict.values())
+        loss.backward()
+        total = loss.detach()
+    else:
+        total = None
+        for lo in range(0, R, ray_chunk):
+            hi = min(lo + ray_chunk, R)
+            outputs = model(ray_bundle[lo:hi])
+            loss_dict = model.get_loss_dict(outputs, {"image": batch["image"][lo:hi]})
+            w = (hi - lo) / float(R)
+            loss = sum(v * w if k in _MEAN_TERMS else v for k, v in loss_dict.items())
+            loss.backward()
+            total = loss.detach() if total is None else total + loss.detach()
+            del outputs, loss_dict, loss  # this chunk's activations are released before the next chunk's forward
     if reducer is not None:
         reducer()
     optimizer.step()
-    return loss.detach()
+    return total

@@ -106,6 +106,8 @@ class ReflectSamplingNeRFNerfField(Field):
 
         self._packed: Optional[Tensor] = None
         self._packed_key = None
+        self._pack_table: Optional[Tensor] = None
+        self._pack_table_key = None
         self._desc: Optional[FieldDesc] = None
         self.mma_mode = _abi.RSN_MMA_F32
 
@@ -176,7 +178,16 @@ class ReflectSamplingNeRFNerfField(Field):
             if self._packed is None or self._packed.numel() * 4 != nbytes or self._packed.device != dev:
                 self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
             ps = self._param_struct()
-            check(lib.rsn_pack_weights(C.byref(desc), C.byref(ps), ptr(self._packed), nbytes, ops._stream()))
+            # one launch for all segments; the job table is re-uploaded only when a pointer or the shape changed
+            tbytes = lib.rsn_pack_table_bytes()
+            if self._pack_table is None or self._pack_table.device != dev:
+                self._pack_table = torch.empty(tbytes, device=dev, dtype=torch.uint8)
+                self._pack_table_key = None
+            tkey = (tuple(p.data_ptr() for p in params), self._packed.data_ptr(), int(self.mma_mode))
+            rebuild = 1 if tkey != self._pack_table_key else 0
+            check(lib.rsn_pack_weights_table(C.byref(desc), C.byref(ps), ptr(self._packed), nbytes,
+                                             ptr(self._pack_table), tbytes, rebuild, ops._stream()))
+            self._pack_table_key = tkey
             self._packed_key = key
         return self._packed
 

@@ -238,9 +238,18 @@ class GetOutputsTrain(torch.autograd.Function):
         jitter = jitter or {}
         bins = bins or {}
 
-        def jit(name, n, S):
+        def jit(name, n, S, rows=None):
+            """the level's uniform draws [n, S+1]: injected ones (validated: the kernel reads n*(S+1) floats) or fresh.
+            Reflect levels also accept draws per ORIGINAL ray [R, S+1]: the rows of this pass's reflected rays are used."""
             t = jitter.get(name)
-            return ops._f32c(t.to(dev)) if t is not None else torch.rand(n, S + 1, device=dev)
+            if t is None:
+                return torch.rand(n, S + 1, device=dev)
+            t = ops._f32c(t.to(dev))
+            if rows is not None and t.shape[0] == R and n != R:
+                t = t[rows[:n].long()].contiguous()
+            if tuple(t.shape) != (n, S + 1):
+                raise ValueError(f"jitter[{name!r}] has shape {tuple(t.shape)}, expected {(n, S + 1)}")
+            return t
 
         def level_bins(name, n, S, sample):
             """the level's (spacing, euclidean) bins: injected ones if given, else the sampler launch `sample()`"""
@@ -290,13 +299,13 @@ class GetOutputsTrain(torch.autograd.Function):
                 lib.rsn_field_forward_inf_train(C.byref(desc), ptr(pk), M, None, ptr(d2), ptr(sq), ptr(bg), C.byref(fs),
                                                 ops._stream())))
             sb_rc, eb_rc = level_bins("reflect_coarse", M, Src, lambda: ops.sample_spaced(
-                M, None, Src, rec.spacing, rec.tan, near2, far2, jit("reflect_coarse", M, Src)))
+                M, None, Src, rec.spacing, rec.tan, near2, far2, jit("reflect_coarse", M, Src, rs["ray_index"])))
             lrc = fld.evaluate_frustums_train(o2, d2, pa2, eb_rc, want_normals=False)
             crc = ops.composite(M, None, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
             ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
             sb_rf, eb_rf = level_bins("reflect_fine", M, Srf, lambda: ops.sample_pdf(
                 M, None, Src, Srf, rec.spacing, rec.tan, model.sampler_reflect_pdf.histogram_padding, near2, far2,
-                crc["weights"], sb_rc, jit("reflect_fine", M, Srf)))
+                crc["weights"], sb_rc, jit("reflect_fine", M, Srf, rs["ray_index"])))
             lrf = fld.evaluate_frustums_train(o2, d2, pa2, eb_rf, want_normals=False)
             crf = ops.composite(M, None, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
             ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])

@@ -500,19 +500,14 @@ def test_train_forward_backward_matches_oracle_autograd(dev, layers, width, samp
 
 
 def test_training_trajectory_and_psnr_match_oracle(dev):
-    """End-to-end: 24 optimisation steps (RAdam, 50-step warm-up schedule, shared rays and jitter) of the HIP path
-    and of the CPU oracle from the same initial weights.  Loss trajectories agree to 1e-4 relative, the PSNR of the
-    rendered held-out rays agrees within 0.1 dB (north-star bound).  A 150-step run of the same harness is recorded
-    in profiles/r01_train_parity_150steps.json (delta 0.001 dB)."""
-    import json
-    import subprocess
-    import sys
+    """End-to-end: 24 optimisation steps (fused RAdam with the reference's decay, 50-step warm-up schedule, shared rays
+    and jitter) of the HIP path and of the CPU oracle from the same initial weights, run IN-PROCESS (tools.train_parity.run).
+    Loss trajectories agree to 1e-4 relative, the PSNR of the rendered held-out rays agrees within 0.1 dB (north-star
+    bound).  The long run of the same harness -- 400 lockstep steps, then the HIP path alone until the render exceeds
+    20 dB -- is recorded in profiles/r02_train_parity.json."""
+    from tools.train_parity import run
 
-    out = subprocess.run([sys.executable, "tools/train_parity.py", "--steps", "24", "--rays", "128", "--samples", "16",
-                          "16", "8", "8"], capture_output=True, text=True, timeout=600,
-                         cwd=__import__("os").path.dirname(__import__("os").path.dirname(__file__)))
-    assert out.returncode == 0, out.stderr[-2000:]
-    res = json.loads(out.stdout.strip().splitlines()[-1])
+    res = run(steps=24, rays=128, samples=(16, 16, 8, 8), verbose=False)
     assert res["max_rel_loss_diff_first10"] <= 1e-4
     assert abs(res["loss_last"][0] - res["loss_last"][1]) <= 1e-3 * abs(res["loss_last"][0])
     assert abs(res["psnr_delta_db"]) <= 0.1
@@ -688,6 +683,36 @@ def test_camera_ray_bundle_chunked_eval(dev):
                                                            c["accumulation_fine"].expand(H, Wd, 3)], dim=1)) <= 1e-6
     assert max_abs(images["depth"].cpu(), torch.cat([depth_panel(c["depth_coarse"], c["accumulation_coarse"]),
                                                     depth_panel(c["depth_fine"], c["accumulation_fine"])], dim=1)) <= 1e-6
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16"])
+@pytest.mark.parametrize("layers,width", [(8, 256), (4, 128), (6, 64)])
+def test_single_launch_packing_equals_per_segment_packing(dev, layers, width, mode):
+    """rsn_pack_weights_table (every segment in one launch, job table in device memory) against rsn_pack_weights (one
+    launch per segment): bit-identical packed buffers, also when the table is re-used for changed parameter values."""
+    import ctypes as C
+
+    from reflect_sampling_nerf_amd._abi import check, load_library, ptr
+
+    lib = load_library()
+    fld, _, _ = make_field(layers, width, dev, seed=5)
+    fld.set_mma_mode(mode)
+    fast = fld.packed_weights().clone()  # the Field packs through the table path
+    desc, ps = fld.field_desc(), fld._param_struct()
+    nbytes = lib.rsn_packed_weights_bytes(C.byref(desc))
+    slow = torch.zeros(nbytes // 4, device=dev)
+    check(lib.rsn_pack_weights(C.byref(desc), C.byref(ps), ptr(slow), nbytes, ops._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(fast.view(torch.int32), slow.view(torch.int32))
+    with torch.no_grad():  # new values, same pointers: the table is NOT rebuilt
+        for p in fld.parameters():
+            p.mul_(1.5).add_(0.01)
+    key_before = fld._pack_table_key
+    fast2 = fld.packed_weights()
+    assert fld._pack_table_key == key_before
+    check(lib.rsn_pack_weights(C.byref(desc), C.byref(ps), ptr(slow), nbytes, ops._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(fast2.view(torch.int32), slow.view(torch.int32)) and not torch.equal(fast2, fast)
 
 
 # ---------------------------------------------------------------------------------------------- edge shapes
@@ -1067,6 +1092,51 @@ def test_baseline_config2_training_step_properties(dev):
     moved = [not torch.equal(a, b.detach()) for a, b in zip(before, params)]
     assert sum(moved) >= len(params) - 2 and all(bool(torch.isfinite(p).all()) for p in params)
     assert g1  # gradients existed
+
+
+def test_chunked_train_step_equals_whole_batch_step(dev):
+    """parallel.train_step(..., ray_chunk=n): gradient accumulation over ray chunks is the whole-batch step (losses, every
+    parameter gradient, the updated parameters), with the live activation memory of one chunk."""
+    from reflect_sampling_nerf_amd.parallel import train_step
+
+    R = 320
+    real_rand = torch.rand
+    results = []
+    try:
+        # the samplers' stratified jitter: a constant, so that chunked and whole-batch runs see the same sample positions
+        torch.rand = lambda *shape, **kw: torch.full(shape, 0.37, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+        for chunk in (None, 96):  # 96 does not divide 320: a ragged last chunk
+            torch.manual_seed(0)
+            cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=16, num_importance_samples=24,
+                                                    num_reflect_coarse_samples=8, num_reflect_importance_samples=8,
+                                                    base_mlp_num_layers=8, base_mlp_layer_width=64)
+            model = cfg.setup(scene_box=None, num_train_data=1)
+            with torch.no_grad():
+                model.field.field_output_density.net.bias += 2.0
+            model.to(dev).train()
+            o, d, pa = cpu_ref.synthetic_rays(R, seed=3)
+            rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev),
+                               nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
+            batch = {"image": real_rand(R, 3, generator=torch.Generator().manual_seed(1)).to(dev)}
+            params = model.get_param_groups()["fields"]
+            opt = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15)
+            peak0 = torch.cuda.max_memory_allocated()
+            torch.cuda.reset_peak_memory_stats()
+            loss = float(train_step(model, rb, batch, opt, None, 100, ray_chunk=chunk))
+            torch.cuda.synchronize()
+            results.append((loss, {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None},
+                            [p.detach().clone() for p in params], torch.cuda.max_memory_allocated()))
+    finally:
+        torch.rand = real_rand
+    (l0, g0, p0, m0), (l1, g1, p1, m1) = results
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert sorted(g0) == sorted(g1)
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * scale + 1e-10, n
+    for a, b in zip(p0, p1):
+        assert float((a - b).abs().max()) <= 1e-6
+    assert m1 < 0.6 * m0, f"chunked peak {m1} vs whole {m0} bytes"  # 96-ray chunks of a 320-ray batch
 
 
 def test_baseline_config3_bf16_properties(dev):
