@@ -697,6 +697,9 @@ def test_single_launch_packing_equals_per_segment_packing(dev, layers, width, mo
     lib = load_library()
     fld, _, _ = make_field(layers, width, dev, seed=5)
     fld.set_mma_mode(mode)
+    fld.packed_weights()  # allocates the buffer; regions no launch writes (split-bf16 copies in f32 mode) get zeros
+    fld._packed.zero_()
+    fld._packed_key = None
     fast = fld.packed_weights().clone()  # the Field packs through the table path
     desc, ps = fld.field_desc(), fld._param_struct()
     nbytes = lib.rsn_packed_weights_bytes(C.byref(desc))
@@ -1120,12 +1123,13 @@ def test_chunked_train_step_equals_whole_batch_step(dev):
             batch = {"image": real_rand(R, 3, generator=torch.Generator().manual_seed(1)).to(dev)}
             params = model.get_param_groups()["fields"]
             opt = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15)
-            peak0 = torch.cuda.max_memory_allocated()
+            torch.cuda.synchronize()
             torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
             loss = float(train_step(model, rb, batch, opt, None, 100, ray_chunk=chunk))
             torch.cuda.synchronize()
             results.append((loss, {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None},
-                            [p.detach().clone() for p in params], torch.cuda.max_memory_allocated()))
+                            [p.detach().clone() for p in params], torch.cuda.max_memory_allocated() - base))
     finally:
         torch.rand = real_rand
     (l0, g0, p0, m0), (l1, g1, p1, m1) = results
