@@ -231,7 +231,7 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
     with torch.no_grad():
         model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised
     model.to(dev).train()
-    model.field.set_mma_mode(args.mma if args.mma in ("f32", "bf16x6") else "f32")
+    model.field.set_mma_mode(args.mma if args.mma in ("f32", "bf16x6", "bf16") else "f32")
     o, d, pa = synthetic_rays(R, seed=rank)  # each rank renders its own rays
     rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.reshape(R, 1).to(dev),
                        nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
@@ -277,9 +277,9 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
         }
         kern = {}
         for key, name, names in (
-                ("forward", "rsn_field_kernel<%d,true,%d>" % (args.width // 32, 1 if args.mma == "bf16x6" else 0),
+                ("forward", "rsn_field_kernel<%d,true,%d>" % (args.width // 32, {"bf16x6": 1, "bf16": 3}.get(args.mma, 0)),
                  ("field_forward_train_normals", "field_forward_train")),
-                ("backward", "rsn_field_bwd_kernel<%d,%d>" % (args.width // 32, 1 if args.mma == "bf16x6" else 0),
+                ("backward", "rsn_field_bwd_kernel<%d,%d>" % (args.width // 32, {"bf16x6": 1, "bf16": 3}.get(args.mma, 0)),
                  ("field_backward", "field_backward_input")),
                 ("wgrad", "rsn_wgrad_kernel", ("weight_grad",))):
             t_ms = sum(ms(n) for n in names)
@@ -289,6 +289,15 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
                          "ms_per_step": t_ms / steps, "algorithmic_flop_per_step": flop[key] / steps,
                          "achieved_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS}
         total_flop = sum(flop.values()) / steps
+        # the same, split by launch kind (primary levels carry the analytic-normal sweep / no input gradient)
+        per_kind = {}
+        for n, fl in (("field_forward_train_normals", 2.0 * (macs["forward"] + macs["normals"])),
+                      ("field_forward_train", 2.0 * macs["forward"]), ("field_backward", 2.0 * macs["backward"]),
+                      ("field_backward_input", 2.0 * macs["backward_input"])):
+            if calls(n):
+                per_kind[n] = {"launches_per_step": calls(n) / steps, "avg_launch_ms": ms(n) / calls(n),
+                               "achieved_tflops": fl * pts(n) / (ms(n) * 1e-3) / 1e12}
+        rec["launch_kinds"] = per_kind
         rec["kernels"] = kern
         rec["algorithmic_flop_per_step"] = total_flop
         rec["flop_formula"] = (
@@ -465,7 +474,7 @@ def main():
                     "train_step": {k: rec[k] for k in ("algorithmic_flop_per_step", "flop_formula", "kernels",
                                                        "end_to_end_tflops", "end_to_end_frac_of_fp32_mfma_peak",
                                                        "other_ms_per_step", "loss", "reflect_ray_fraction",
-                                                       "host_syncs_in_reducer", "peak_device_memory_gb", "ray_chunk")},
+                                                       "host_syncs_in_reducer", "peak_device_memory_gb", "ray_chunk", "launch_kinds")},
                 }
             if world == 1 and not args.no_secondary and args.mma == "f32":
                 # secondary legs (untimed for the headline): configs[1] eval level and the configs[2] training shape
@@ -475,7 +484,15 @@ def main():
                 x6_args = argparse.Namespace(**{**vars(args), "mma": "bf16x6"})
                 x6 = run_train(pkg, x6_args, dev, rank, world, None, share, samples, min(args.steps, 10),
                                min(max(args.warmup, 1), 3), dog, time_kernels=False)
+                bf_args = argparse.Namespace(**{**vars(args), "mma": "bf16"})
+                bf = run_train(pkg, bf_args, dev, rank, world, None, share, samples, min(args.steps, 10),
+                               min(max(args.warmup, 1), 3), dog, time_kernels=False)
                 line["eval_level"] = lv
+                line["train_step_bf16_sweeps"] = {
+                    "workload": "the headline step in REDUCED precision (opt-in; the reference itself trains under fp16 "
+                                "autocast, config.py:33): forward / backward sweeps with plain bf16 MFMA operands and fp32 "
+                                "accumulation, weight gradients exact fp32 over fp32-saved activations",
+                    **{k: bf[k] for k in ("value", "unit", "ms_per_step", "steps")}}
                 line["train_step_bf16x6_sweeps"] = {
                     "workload": "the headline step with the forward / backward sweeps on split-bf16 MFMA (3-way split, 6 "
                                 "products, fp32 accumulate: fp32-equivalent, opt-in); weight gradients stay exact fp32",

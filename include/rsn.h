@@ -110,6 +110,8 @@ typedef struct rsn_field_saved {
   float* heads;   /* [N,8]    raw normal head (3), raw roughness head (1), mid RGB (3), pad                  */
   float* normals; /* [N,3]    OUT: analytic normals -normalize(d raw_density/d mean) (field.py:146-147),     *
                    *          or NULL to skip the sweep (reflect levels, model.py:295,321)                    */
+  uint32_t* relu_bits; /* [L+1,N,2,max(W/64,2)] ReLU masks (pre-activation > 0) of trunk layer l (l < L) and of the mlp_mid *
+                   *          hidden layer (l = L), bit-packed per lane half: what the dX sweeps mask by            */
 } rsn_field_saved;
 
 int rsn_abi_version(void);

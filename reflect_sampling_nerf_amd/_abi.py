@@ -53,7 +53,7 @@ class FieldOutputs(C.Structure):
 
 
 class FieldSaved(C.Structure):
-    _fields_ = [(n, _fp) for n in ("enc", "act", "bott", "sh", "hid", "heads", "normals")]
+    _fields_ = [(n, _fp) for n in ("enc", "act", "bott", "sh", "hid", "heads", "normals", "relu_bits")]
 
 
 class FieldGradsIn(C.Structure):
@@ -160,6 +160,7 @@ def load_library(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("RSN_LIBRARY", path)  # tools/: an experimental build of the same ABI (tools/_variant.py)
     if not os.path.exists(path):
         raise RsnError(
             f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "

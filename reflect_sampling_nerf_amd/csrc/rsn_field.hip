@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     const long long p = p0 + m;
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
+    // training: this lane's slot in the ReLU bit masks of layer l (rsn_field_saved.relu_bits: [L+1][N][2][NB/2] words)
+    auto bits_at = [&](int l) -> unsigned* {
+      return a.saved.relu_bits + ((((long long)l * (a.act_stride / W)) + pc) * 2 + h) * (NB / 2 > 2 ? NB / 2 : 2);
+    };
 
     float mc[3] = {0.0f, 0.0f, 0.0f}, vc[3] = {0.0f, 0.0f, 0.0f}, vd[3] = {0.0f, 0.0f, 0.0f};
     bool has_cov = true, has_dir = true;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         pre_mode<MODE, NB>(wpre, pk + a.L.w_x[l], ln);
         // ReLU between layers; the accumulators restart from layer l's bias
         store_act_init<NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (l - 1) * a.act_stride + pc * W : nullptr,
-                                 h, pk + a.L.b[l]);
+                                 h, pk + a.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
         RSN_T(3);
         gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, ln);
         RSN_T(4);
@@ -211,7 +215,8 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       }
       // out_activation = ReLU
       pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, ln);
-      store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (a.num_layers - 1) * a.act_stride + pc * W : nullptr, h);
+      store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (a.num_layers - 1) * a.act_stride + pc * W : nullptr, h,
+                              (TRAIN && a.saved.relu_bits && valid) ? bits_at(a.num_layers - 1) : nullptr);
       RSN_T(3);
     }
     }  // mode != RSN_MODE_EMB
@@ -310,7 +315,8 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       gemm_mode_run<MODE, 4>(accm, wmx, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, ln);
       RSN_T(8);
       pre_mode<MODE, 1>(wrgb, pk + a.L.w_rgb, ln);
-      store_act<4, 4, true>(accm, X, (TRAIN && a.saved.hid && valid) ? a.saved.hid + pc * 128 : nullptr, h);
+      store_act<4, 4, true>(accm, X, (TRAIN && a.saved.hid && valid) ? a.saved.hid + pc * 128 : nullptr, h,
+                            (TRAIN && a.saved.relu_bits && valid) ? bits_at(a.num_layers) : nullptr);
       RSN_T(3);
     }
     {
@@ -343,16 +349,21 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     // saved activations; the encoded-input gradient accumulates in 4 extra blocks (slot order), and the chain
     // through sin(2 pi x f [+ pi/2]) * exp(-var f^2 / 2) is closed per lane (the covariance is a constant here,
     // exactly like the reference, which sets requires_grad on the mean after contraction).
-    if (TRAIN && a.saved.normals && a.saved.act) {
+    if (TRAIN && a.saved.normals && a.saved.relu_bits) {
       const float* __restrict__ wd = pk + a.L.v_density;
       {
-        const float* embp = a.saved.act + (long long)(a.num_layers - 1) * a.act_stride + pc * W;
-#pragma unroll 4
+        // seed: the density-head row masked by the embedding's ReLU (bits of the last trunk layer)
+        const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(a.num_layers - 1));
+#pragma unroll
         for (int it = 0; it < NB * 4; ++it) {
-          const float4 e = *reinterpret_cast<const float4*>(embp + it * 8 + 4 * h);
           const float4 w = *reinterpret_cast<const float4*>(wd + it * 8 + 4 * h);
-          X[it * 64] = make_float4(e.x > 0.0f ? w.x : 0.0f, e.y > 0.0f ? w.y : 0.0f, e.z > 0.0f ? w.z : 0.0f,
-                                   e.w > 0.0f ? w.w : 0.0f);
+          const int word = mb.w[it / 8];
+          const int base = ((it / 4) & 1) * 16 + 4 * (it & 3);
+          X[it * 64] = make_float4(
+              __uint_as_float(__float_as_uint(w.x) & (unsigned)__builtin_amdgcn_sbfe(word, base + 0, 1)),
+              __uint_as_float(__float_as_uint(w.y) & (unsigned)__builtin_amdgcn_sbfe(word, base + 1, 1)),
+              __uint_as_float(__float_as_uint(w.z) & (unsigned)__builtin_amdgcn_sbfe(word, base + 2, 1)),
+              __uint_as_float(__float_as_uint(w.w) & (unsigned)__builtin_amdgcn_sbfe(word, base + 3, 1)));
         }
       }
       f32x16 eacc[4];
@@ -360,13 +371,12 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
 #pragma unroll 1
       for (int l = a.num_layers - 1; l >= 1; --l) {
         if (l == a.skip_layer) gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, ln);
-        float4 mk[NB * 4];
-        load_mask<NB>(mk, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
+        const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l - 1));
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[NB];
         zero_acc<NB>(acc);
         gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
-        store_masked_pre<NB>(acc, X, mk, h);
+        store_masked_bits<NB>(acc, X, mb, h);
       }
       gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, ln);
       store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
@@ -446,6 +456,8 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
   do {                                                                                                           \
     if (train && mode == RSN_MMA_BF16X6)                                                                        \
       hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
+    else if (train && mode == RSN_MMA_BF16)  /* reduced-precision training: plain bf16 operands, fp32 accumulate */ \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
     else if (train)  /* BF16X3 is an eval-only opt-in: training falls back to exact fp32 */                      \
       hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
     else if (mode == RSN_MMA_BF16X6)                                                                            \
@@ -492,7 +504,7 @@ extern "C" int rsn_field_forward_frustum_train(const rsn_field_desc* desc, const
   RSN_REQUIRE(n_rays >= 0 && n_samples >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d n_samples=%d", n_rays, n_samples);
   RSN_REQUIRE(n_rays == 0 || (origins && directions && pixel_area && euclid_bins), RSN_ERR_INVALID_ARGUMENT,
               "a ray input pointer is NULL");
-  RSN_REQUIRE(saved->act && saved->enc && saved->bott && saved->sh && saved->hid && saved->heads,
+  RSN_REQUIRE(saved->act && saved->enc && saved->bott && saved->sh && saved->hid && saved->heads && saved->relu_bits,
               RSN_ERR_INVALID_ARGUMENT, "training needs every saved-activation buffer (normals may be NULL)");
   FieldArgs a = {};
   a.packed = packed;
@@ -525,7 +537,7 @@ extern "C" int rsn_field_forward_inf_train(const rsn_field_desc* desc, const flo
   RSN_REQUIRE(desc && saved, RSN_ERR_INVALID_ARGUMENT, "desc/saved is NULL");
   RSN_REQUIRE(n_rays >= 0, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
   RSN_REQUIRE(n_rays == 0 || (directions && sqradius && out_rgb), RSN_ERR_INVALID_ARGUMENT, "an input pointer is NULL");
-  RSN_REQUIRE(saved->act && saved->enc && saved->bott && saved->sh && saved->hid && saved->heads,
+  RSN_REQUIRE(saved->act && saved->enc && saved->bott && saved->sh && saved->hid && saved->heads && saved->relu_bits,
               RSN_ERR_INVALID_ARGUMENT, "training needs every saved-activation buffer");
   FieldArgs a = {};
   a.packed = packed;

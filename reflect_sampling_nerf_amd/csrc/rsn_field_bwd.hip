@@ -136,6 +136,9 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     const long long pc = valid ? p : n_points - 1;
     const float live = valid ? 1.0f : 0.0f;  // padded lanes contribute zero gradients
 
+    auto bits_at = [&](int l) -> const unsigned* {  // rsn_field_saved.relu_bits: [L+1][N][2][NB/2] words
+      return a.saved.relu_bits + ((((long long)l * (a.act_stride / W)) + pc) * 2 + h) * (NB / 2 > 2 ? NB / 2 : 2);
+    };
     // ---------------- per-sample epilogue gradients -----------------
     float gcol[3] = {0.0f, 0.0f, 0.0f};
     if (a.gin.color) {
@@ -164,13 +167,12 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     X[0] = (h == 1) ? make_float4(dz_rgb[0], dz_rgb[1], dz_rgb[2], 0.0f) : zero4;
     X[64] = zero4; X[128] = zero4; X[192] = zero4;
     {
-      float4 mk[16];
-      load_mask<4>(mk, a.saved.hid + pc * 128, h);
+      const ReluBits<4> mb = load_relu_bits<4>(bits_at(a.num_layers));
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[4];
       zero_acc<4>(acc);
       gemm_mode<MODE, 4>(acc, pk + a.L.wT_rgb, pk + a.L.hT_rgb, X, 4, ln);
-      store_masked_pre<4>(acc, X, mk, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
+      store_masked_bits<4>(acc, X, mb, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
@@ -230,13 +232,12 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
         *reinterpret_cast<float4*>(a.gout.dz_heads + pc * 16 + 8 + 4 * h) = q1;
       }
       const int l = a.num_layers - 1;
-      float4 mk[NB * 4];
-      load_mask<NB>(mk, a.saved.act + (long long)l * a.act_stride + pc * W, h);
+      const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l));
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_bh, pk + a.L.hT_bh, X, NB * 4 + 4, ln);
-      store_masked_pre<NB>(acc, X, mk, h, valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
+      store_masked_bits<NB>(acc, X, mb, h, valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
     f32x16 eacc[4];
@@ -245,13 +246,16 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     for (int l = a.num_layers - 1; l >= 1; --l) {
       if (a.need_input_grad && l == a.skip_layer)
         gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, ln);
-      float4 mk[NB * 4];
-      load_mask<NB>(mk, a.saved.act + (long long)(l - 1) * a.act_stride + pc * W, h);
+      const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l - 1));
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
-      store_masked_pre<NB>(acc, X, mk, h, valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
+#ifdef RSN_BWD_NO_DYSTORE  // timing diagnostic (tools/train_diag.sh): wrong results
+      store_masked_bits<NB>(acc, X, mb, h, nullptr);
+#else
+      store_masked_bits<NB>(acc, X, mb, h, valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
+#endif
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
     if (a.need_input_grad) {
@@ -300,8 +304,8 @@ static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
   int rc = rsn_compute_layout(d, &a.L);
   if (rc != RSN_OK) return rc;
   RSN_REQUIRE(a.packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "packed weights pointer is NULL");
-  RSN_REQUIRE(a.saved.act && a.saved.hid && a.saved.heads && a.gout.dy, RSN_ERR_INVALID_ARGUMENT,
-              "saved activations (act, hid, heads) and gout.dy are required");
+  RSN_REQUIRE(a.saved.relu_bits && a.saved.heads && a.gout.dy, RSN_ERR_INVALID_ARGUMENT,
+              "saved relu_bits / heads and gout.dy are required");
   RSN_REQUIRE(!a.need_input_grad || (a.saved.enc && a.gout.d_input), RSN_ERR_INVALID_ARGUMENT,
               "need_input_grad needs saved.enc and gout.d_input");
   RSN_REQUIRE(a.mode == RSN_MODE_INF || (a.fwd.raw_density && a.fwd.diff && a.fwd.tint), RSN_ERR_INVALID_ARGUMENT,
@@ -329,6 +333,8 @@ static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
 #define RSN_LAUNCH_BWD(NBV)                                                                                  \
   do {                                                                                                       \
     if (x6) hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
+    else if (d->mma_mode == RSN_MMA_BF16)  /* reduced-precision training sweeps (bf16 operands, fp32 accumulate) */ \
+      hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);              \
     else hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);       \
   } while (0)
   switch (d->width) {

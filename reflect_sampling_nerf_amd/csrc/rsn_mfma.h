@@ -337,13 +337,93 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
 }
 
+// ReLU sign bits of one lane: bit nb*16 + r = (accumulator register r of block nb, the layer's pre-activation) > 0,
+// packed into NBO/2 words (rsn_field_saved.relu_bits).  The dX sweeps mask by these bits instead of re-reading the
+// saved fp32 activations (1 KiB per point and layer -> 32 B; 124 fewer live registers in the sweeps).
+__device__ __forceinline__ unsigned relu_bits16(const f32x16& a) {
+  unsigned b = 0u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = (int)__float_as_uint(a[r]);          // pre-activation x > 0  <=>  its bit pattern, as an int, > 0
+    b |= (unsigned)min(max(t, 0), 1) << r;               // v_med3_i32 + v_lshl_or_b32
+  }
+  return b;
+}
+
+template <int NBO>
+__device__ __forceinline__ void store_relu_bits(const f32x16 (&acc)[NBO], unsigned* bits) {
+  if (NBO >= 8) {
+#pragma unroll
+    for (int w4 = 0; w4 < NBO / 8; ++w4) {
+      uint4 v;
+      v.x = relu_bits16(acc[w4 * 8 + 0]) | (relu_bits16(acc[w4 * 8 + 1]) << 16);
+      v.y = relu_bits16(acc[w4 * 8 + 2]) | (relu_bits16(acc[w4 * 8 + 3]) << 16);
+      v.z = relu_bits16(acc[w4 * 8 + 4]) | (relu_bits16(acc[w4 * 8 + 5]) << 16);
+      v.w = relu_bits16(acc[w4 * 8 + 6]) | (relu_bits16(acc[w4 * 8 + 7]) << 16);
+      *reinterpret_cast<uint4*>(bits + w4 * 4) = v;
+    }
+  } else {
+#pragma unroll
+    for (int w = 0; w < NBO / 2; ++w) bits[w] = relu_bits16(acc[2 * w]) | (relu_bits16(acc[2 * w + 1]) << 16);
+  }
+}
+
+// the lane's NBO/2 mask words of one layer (issued BEFORE the layer's GEMM, consumed by store_masked_bits after it)
+template <int NBO>
+struct ReluBits {
+  unsigned w[NBO / 2];
+};
+
+template <int NBO>
+__device__ __forceinline__ ReluBits<NBO> load_relu_bits(const unsigned* __restrict__ bits) {
+  ReluBits<NBO> m;
+  if (NBO >= 8) {
+#pragma unroll
+    for (int w4 = 0; w4 < NBO / 8; ++w4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(bits + w4 * 4);
+      m.w[w4 * 4 + 0] = v.x; m.w[w4 * 4 + 1] = v.y; m.w[w4 * 4 + 2] = v.z; m.w[w4 * 4 + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int w = 0; w < NBO / 2; ++w) m.w[w] = bits[w];
+  }
+  return m;
+}
+
+// dX-sweep epilogue on mask bits: X[it][lane] = bit ? acc : 0 (v_bfe_i32 gives 0 / -1, one v_and applies it);
+// optionally also stored to row `save` (backward pass: the layer's pre-activation gradient for the weight gradients)
+template <int NBO>
+__device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], float4* xl, const ReluBits<NBO>& m, int h,
+                                                  float* save = nullptr) {
+#pragma unroll
+  for (int nb = 0; nb < NBO; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int word = m.w[nb / 2];
+      const int base = (nb & 1) * 16 + 4 * q;
+      float4 v;
+      v.x = __uint_as_float(__float_as_uint(acc[nb][4 * q + 0]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 0, 1));
+      v.y = __uint_as_float(__float_as_uint(acc[nb][4 * q + 1]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 1, 1));
+      v.z = __uint_as_float(__float_as_uint(acc[nb][4 * q + 2]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 2, 1));
+      v.w = __uint_as_float(__float_as_uint(acc[nb][4 * q + 3]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 3, 1));
+      xl[(nb * 4 + q) * 64] = v;
+      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+    }
+}
+
 // X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3])   (bias already inside acc, see init_acc).
 // save (training): the same float4 also goes to row `save` of a row-major [N, 32*NBS] activation buffer
 // (this lane's point; the four q of one nb complete one 128-B line per row).
 template <int NBO, int NBS, bool RELU>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, float* save = nullptr, int h = 0) {
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, float* save = nullptr, int h = 0,
+                                          unsigned* bits = nullptr) {
+  unsigned bw[NBS / 2 > 0 ? NBS / 2 : 1];
 #pragma unroll
-  for (int nb = 0; nb < NBS; ++nb)
+  for (int nb = 0; nb < NBS; ++nb) {
+    if (RELU && bits) {  // the block's 16 mask bits, taken while its accumulators are being read anyway
+      const unsigned b16 = relu_bits16(acc[nb]);
+      if (nb & 1) bw[nb / 2] |= b16 << 16; else bw[nb / 2] = b16;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
@@ -356,15 +436,31 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
       xl[(nb * 4 + q) * 64] = v;
       if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
     }
+  }
+  if (RELU && bits) {
+    if (NBS >= 8) {
+#pragma unroll
+      for (int w4 = 0; w4 < NBS / 8; ++w4)
+        *reinterpret_cast<uint4*>(bits + w4 * 4) = make_uint4(bw[w4 * 4], bw[w4 * 4 + 1], bw[w4 * 4 + 2], bw[w4 * 4 + 3]);
+    } else {
+#pragma unroll
+      for (int w = 0; w < NBS / 2; ++w) bits[w] = bw[w];
+    }
+  }
 }
 
 // store_act of one layer fused with init_acc of the next (same NBO): block by block the accumulators are read out and
 // immediately re-loaded with the next layer's bias, so the bias round trip hides under the rest of the epilogue.
 template <int NBO, bool RELU>
 __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, float* save, int h,
-                                               const float* __restrict__ bias) {
+                                               const float* __restrict__ bias, unsigned* bits = nullptr) {
+  unsigned bw[NBO / 2 > 0 ? NBO / 2 : 1];
 #pragma unroll
-  for (int nb = 0; nb < NBO; ++nb)
+  for (int nb = 0; nb < NBO; ++nb) {
+    if (RELU && bits) {
+      const unsigned b16 = relu_bits16(acc[nb]);
+      if (nb & 1) bw[nb / 2] |= b16 << 16; else bw[nb / 2] = b16;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
@@ -382,6 +478,17 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, f
       acc[nb][4 * q + 2] = bv.z;
       acc[nb][4 * q + 3] = bv.w;
     }
+  }
+  if (RELU && bits) {
+    if (NBO >= 8) {
+#pragma unroll
+      for (int w4 = 0; w4 < NBO / 8; ++w4)
+        *reinterpret_cast<uint4*>(bits + w4 * 4) = make_uint4(bw[w4 * 4], bw[w4 * 4 + 1], bw[w4 * 4 + 2], bw[w4 * 4 + 3]);
+    } else {
+#pragma unroll
+      for (int w = 0; w < NBO / 2; ++w) bits[w] = bw[w];
+    }
+  }
 }
 
 // Prefetch of the ReLU-mask rows (saved post-ReLU activations) of a dX-sweep layer: issued BEFORE the layer's GEMM so

@@ -224,7 +224,7 @@ class ReflectSamplingNeRFNerfField(Field):
         level = {"sigma": f(R, S), "color": f(R, S, 3), "pred_normals": f(R, S, 3), "n_dot_d": f(R, S),
                  "diff": f(R, S, 3), "tint": f(R, S, 3), "roughness": f(R, S), "raw_density": f(R, S)}
         saved = {"enc": f(N, 104), "act": f(L, N, W), "bott": f(N, W), "sh": f(N, 40), "hid": f(N, 128),
-                 "heads": f(N, 8)}
+                 "heads": f(N, 8), "relu_bits": torch.empty(L + 1, N, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
         if want_normals:
             saved["normals"] = f(R, S, 3)
         fo = ops.field_outputs_struct(level)

@@ -88,7 +88,7 @@ def _composite_backward(n, S, background, flags, detach_w, level, eb, weights, g
 
 def _saved_struct(saved: Dict[str, Tensor]) -> FieldSaved:
     fs = FieldSaved()
-    for k in ("enc", "act", "bott", "sh", "hid", "heads", "normals"):
+    for k in ("enc", "act", "bott", "sh", "hid", "heads", "normals", "relu_bits"):
         setattr(fs, k, ptr(saved.get(k)))
     return fs
 
@@ -290,7 +290,7 @@ class GetOutputsTrain(torch.autograd.Function):
             W, L = fld.width, fld.mlp_base.num_layers
             f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
             inf_saved = {"enc": f(M, 104), "act": f(L, M, W), "bott": f(M, W), "sh": f(M, 40), "hid": f(M, 128),
-                         "heads": f(M, 8)}
+                         "heads": f(M, 8), "relu_bits": torch.empty(L + 1, M, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
             bg = f(M, 3)
             desc = fld.field_desc()
             fs = _saved_struct(inf_saved)

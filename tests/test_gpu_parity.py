@@ -1097,6 +1097,45 @@ def test_baseline_config2_training_step_properties(dev):
     assert g1  # gradients existed
 
 
+def test_reduced_precision_training_bf16_sweeps(dev):
+    """Opt-in reduced-precision training (the reference trains under autocast, config.py:33): with mma mode "bf16" the
+    training forward and the backward sweeps run on plain bf16 MFMA operands (fp32 accumulation, fp32 saved activations,
+    exact-fp32 weight-gradient kernel).  Against the exact-fp32 HIP step on the same rays and jitter: rendered outputs
+    within the bf16 tolerance, every parameter gradient in direction (cosine >= 0.99) and size (rel-L2 <= 8e-2)."""
+    R, samples = 96, (16, 16, 8, 8)
+    grads, outs = {}, {}
+    g = torch.Generator().manual_seed(3)
+    jit = {"coarse": torch.rand(R, 17, generator=g), "fine": torch.rand(R, 17, generator=g),
+           "reflect_coarse": torch.rand(R, 9, generator=g), "reflect_fine": torch.rand(R, 9, generator=g)}
+    image = torch.rand(R, 3, generator=g).to(dev)
+    for mode in ("f32", "bf16"):
+        torch.manual_seed(11)
+        cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=16, num_importance_samples=16,
+                                                num_reflect_coarse_samples=8, num_reflect_importance_samples=8)
+        model = cfg.setup(scene_box=None, num_train_data=1)
+        with torch.no_grad():
+            model.field.field_output_density.net.bias += 2.0
+        model.to(dev).train()
+        model.field.set_mma_mode(mode)
+        o, d, pa = cpu_ref.synthetic_rays(R, seed=21)
+        rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev),
+                           nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
+        out = model._get_outputs_train(rb, jitter=jit)
+        sum(model.get_loss_dict(out, {"image": image}).values()).backward()
+        torch.cuda.synchronize()
+        grads[mode] = {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None}
+        outs[mode] = {k: v.detach().clone() for k, v in out.items() if v.dtype.is_floating_point}
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "accumulation_fine"):
+        assert max_abs(outs["bf16"][k], outs["f32"][k]) <= 3e-2, k
+    assert sorted(grads["bf16"]) == sorted(grads["f32"])
+    for n, gr in grads["f32"].items():
+        a, b = grads["bf16"][n].flatten().double(), gr.flatten().double()
+        assert bool(torch.isfinite(a).all()), n
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+        rel = float((a - b).norm() / (b.norm() + 1e-300))
+        assert cos >= 0.99 and rel <= 8e-2, f"{n}: cos {cos:.5f} rel-L2 {rel:.3e}"
+
+
 def test_chunked_train_step_equals_whole_batch_step(dev):
     """parallel.train_step(..., ray_chunk=n): gradient accumulation over ray chunks is the whole-batch step (losses, every
     parameter gradient, the updated parameters), with the live activation memory of one chunk."""

@@ -60,7 +60,7 @@ def loss_terms(out, image):
 
 
 def run(steps=120, oracle_steps=None, rays=256, width=64, layers=8, samples=(32, 32, 16, 16), eval_rays=1024,
-        eval_every=0, json_path="", verbose=True, oracle_tail=0):
+        eval_every=0, json_path="", verbose=True, oracle_tail=0, tail_eval_every=0, save_state=""):
     import reflect_sampling_nerf_amd as pkg
     from oracle import cpu_ref
     from reflect_sampling_nerf_amd.parallel import apply_loss_warmup
@@ -113,7 +113,24 @@ def run(steps=120, oracle_steps=None, rays=256, width=64, layers=8, samples=(32,
                 opt_c.state[p_c] = {"step": torch.tensor(float(opt_g.step_count)), "exp_avg": m1.detach().cpu().clone(),
                                     "exp_avg_sq": m2.detach().cpu().clone()}
             og = eval_hip()
-            checkpoints.append({"step": step, "psnr_hip": psnr(og["mid_rgb_fine"].cpu(), ergb), "note": "oracle resumes from the HIP state here"})
+            with torch.no_grad():  # the two renders of the SAME trained weights (SURVEY 8(d) PSNR (i))
+                oc = cpu_ref.get_outputs({k: v.detach() for k, v in P.items()}, fs, ms, eo, ed, epa, near(eval_rays),
+                                         far(eval_rays), training=False)
+            checkpoints.append({"step": step, "psnr_hip": psnr(og["mid_rgb_fine"].cpu(), ergb),
+                                "psnr_oracle_same_weights": psnr(oc["mid_rgb_fine"], ergb),
+                                "psnr_hip_vs_oracle_render_same_weights": psnr(og["mid_rgb_fine"].cpu(), oc["mid_rgb_fine"]),
+                                "max_abs_render_diff_same_weights": float((og["mid_rgb_fine"].cpu() - oc["mid_rgb_fine"]).abs().max()),
+                                "mask_flips_same_weights": int((og["mask"].cpu() != oc["mask"]).sum()),
+                                "note": "oracle resumes from the HIP state here"})
+            if save_state:  # for tools/chaos_probe.py (CPU): parameters, RAdam moments, step, the batch generator's state
+                import numpy as np
+                os.makedirs(os.path.dirname(os.path.abspath(save_state)), exist_ok=True)
+                arrs = {"param/" + n: P[n].detach().numpy() for n in names}
+                for n, m1, m2 in zip(names, opt_g.exp_avg, opt_g.exp_avg_sq):
+                    arrs["m1/" + n], arrs["m2/" + n] = m1.detach().cpu().numpy(), m2.detach().cpu().numpy()
+                arrs["step"] = np.array([opt_g.step_count]); arrs["gen_state"] = gen.get_state().numpy()
+                arrs["meta"] = np.frombuffer(json.dumps({"rays": R, "samples": S, "layers": layers, "width": width}).encode(), dtype=np.uint8)
+                np.savez_compressed(save_state, **arrs)
             if verbose:
                 print("checkpoint", json.dumps(checkpoints[-1]), flush=True)
         o, d, pa, rgb = scene_rays(R, gen)
@@ -152,11 +169,13 @@ def run(steps=120, oracle_steps=None, rays=256, width=64, layers=8, samples=(32,
         if verbose and (step % 50 == 0 or step == steps - 1):
             print(f"step {step:5d} loss hip {float(lg):.6f}" + (f" cpu {float(lc):.6f} rel {abs(float(lc)-float(lg))/abs(float(lc)):.2e}" if lc is not None else ""), flush=True)
         at_end_of_lockstep = step == oracle_steps - 1 or (tail_start is not None and step == steps - 1)
-        if at_end_of_lockstep or (eval_every and step % eval_every == eval_every - 1) or step == steps - 1:
+        in_tail = tail_start is not None and step >= tail_start
+        if at_end_of_lockstep or (eval_every and step % eval_every == eval_every - 1) or step == steps - 1 or \
+                (in_tail and tail_eval_every and (step - tail_start) % tail_eval_every == tail_eval_every - 1):
             og = eval_hip()
             cp = {"step": step + 1, "psnr_hip": psnr(og["mid_rgb_fine"].cpu(), ergb),
                   "psnr_hip_reflect_fine": psnr(og["mid_reflect_fine"].cpu(), ergb)}
-            if at_end_of_lockstep:
+            if at_end_of_lockstep or in_tail:
                 with torch.no_grad():
                     oc = cpu_ref.get_outputs({k: v.detach() for k, v in P.items()}, fs, ms, eo, ed, epa, near(eval_rays),
                                              far(eval_rays), training=False)
@@ -166,12 +185,19 @@ def run(steps=120, oracle_steps=None, rays=256, width=64, layers=8, samples=(32,
             checkpoints.append(cp)
             if verbose:
                 print("checkpoint", json.dumps(cp), flush=True)
+            if json_path:  # partial results survive a time limit
+                os.makedirs(os.path.dirname(os.path.abspath(json_path)), exist_ok=True)
+                with open(json_path, "w") as f:
+                    json.dump({"partial": True, "checkpoints": checkpoints, "history": hist}, f)
     lock = [h for h in hist if h[1] is not None]
     at_lock = [c for c in checkpoints if "psnr_oracle" in c][-1]  # the last lockstep window's end
     tail = [h for h in lock if tail_start is not None and h[0] >= tail_start]
+    tail_cps = [c for c in checkpoints if tail_start is not None and c["step"] > tail_start and "psnr_oracle" in c]
     res = {"steps": steps, "oracle_steps": oracle_steps, "oracle_tail": oracle_tail, "rays": R, "samples": S,
            "field": f"{layers}x{width}",
            "max_rel_loss_diff_tail": max((abs(a - b) / abs(a) for _, a, b in tail), default=None),
+           "tail_mean_psnr_hip": (sum(c["psnr_hip"] for c in tail_cps) / len(tail_cps)) if tail_cps else None,
+           "tail_mean_psnr_oracle": (sum(c["psnr_oracle"] for c in tail_cps) / len(tail_cps)) if tail_cps else None,
            "psnr_hip": checkpoints[-1]["psnr_hip"], "psnr_hip_at_lockstep_end": at_lock["psnr_hip"],
            "psnr_oracle": at_lock["psnr_oracle"], "psnr_delta_db": at_lock["psnr_delta_db"],
            "psnr_hip_vs_oracle_render": at_lock["psnr_hip_vs_oracle_render"],
@@ -197,11 +223,14 @@ def main():
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--samples", type=int, nargs=4, default=[32, 32, 16, 16])
     ap.add_argument("--oracle-tail", type=int, default=0, help="final steps in lockstep with the oracle resumed from the HIP state")
+    ap.add_argument("--tail-eval-every", type=int, default=0, help="evaluate both pipelines every n steps of the tail window")
+    ap.add_argument("--save-state", default="", help="npz with the state at the start of the tail window (tools/chaos_probe.py)")
     ap.add_argument("--eval-every", type=int, default=0)
     ap.add_argument("--json", default="")
     args = ap.parse_args()
     run(steps=args.steps, oracle_steps=args.oracle_steps, rays=args.rays, width=args.width, layers=args.layers,
-        samples=tuple(args.samples), eval_every=args.eval_every, json_path=args.json, oracle_tail=args.oracle_tail)
+        samples=tuple(args.samples), eval_every=args.eval_every, json_path=args.json, oracle_tail=args.oracle_tail,
+        tail_eval_every=args.tail_eval_every, save_state=args.save_state)
 
 
 if __name__ == "__main__":
