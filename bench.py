@@ -203,7 +203,8 @@ def newest_profile_traffic(kernel_name, rays, samples):
         for fn in sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_summary.json")):
             with open(os.path.join(REPO, "profiles", fn)) as fh:
                 js = json.load(fh)
-            if js.get("kernel") == kernel_name and js.get("rays", 4096) == rays and js.get("samples", 128) == samples \
+            if js.get("kernel", "").replace(" ", "") == kernel_name.replace(" ", "") and js.get("rays", 4096) == rays \
+                    and js.get("samples", 128) == samples \
                     and js.get("hbm_traffic_bytes_per_launch") is not None:
                 traffic = js["hbm_traffic_bytes_per_launch"]
     except (OSError, ValueError):
