@@ -69,7 +69,7 @@ struct RsnPackedLayout {
   size_t total;                       // floats
 };
 #ifndef RSN_RING_GROUP_FRAGS
-#define RSN_RING_GROUP_FRAGS 8
+#define RSN_RING_GROUP_FRAGS 16
 #endif
 
 int rsn_compute_layout(const rsn_field_desc* desc, RsnPackedLayout* L);

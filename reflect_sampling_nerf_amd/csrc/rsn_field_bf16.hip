@@ -314,6 +314,28 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_kernel(const FieldArgs 
   }
 }
 
+// bf16-mode activations: sigmoid / softplus on v_exp_f32 / v_log_f32 / v_rcp_f32 (~1e-6 relative) instead of the
+// correctly-rounded library forms -- their results are weighed against bf16 GEMM rounding (2^-9) in this mode
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_softplus(float x) {
+  return x > 20.0f ? x : 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.4426950408889634f * x));
+}
+// sin / cos with the exact fp32 Cody-Waite reduction of sincos_big and degree-5 / degree-6 least-squares polynomials (4e-6 / 2e-7 absolute
+// on |r| <= 0.87): the feature is rounded to bf16 next
+__device__ __forceinline__ float sincos_bf16(float a, int quad) {
+  const float q = rintf(a * 0.63661977236758134308f);
+  float r = __builtin_fmaf(-q, 1.5707963705062866f, a);
+  r = __builtin_fmaf(-q, -4.371138828673793e-08f, r);
+  const int n = (int)q + quad;
+  const float s = r * r;
+  const float ps = r + r * s * (-0.16661735f + s * 8.12778e-3f);
+  const float pc = 1.0f + s * (-0.49999845f + s * (4.165309e-2f + s * -1.35546e-3f));
+  const float v = (n & 1) ? pc : ps;
+  return (n & 2) ? -v : v;
+}
+
 // ================================================================================================
 // Width 256 (the BASELINE network): the weight stream is SHARED by the workgroup through an LDS ring.
 //
@@ -336,7 +358,9 @@ __global__ __launch_bounds__(256, 2) void rsn_field_bf16_kernel(const FieldArgs 
 // ================================================================================================
 #define RING_ENC_KS ((RSN_ENC_K16 * 8 + RSN_RING_GROUP_FRAGS - 1) / RSN_RING_GROUP_FRAGS * RSN_RING_GROUP_FRAGS / 8)  // enc K-steps incl. padding
 #define RING_RGB_KS (RSN_RING_GROUP_FRAGS == 16 ? 16 : 8)
+#ifndef RING_FIFO
 #define RING_FIFO 4   // fragments read from the ring ahead of their MFMA (registers: 4 x 4 VGPRs)
+#endif
 #define RING_GROUP_BYTES (RSN_RING_GROUP_FRAGS * 1024)
 #define RING_STASH_BYTES (RSN_ENC_K16 * 1024)          // per wave: encoded inputs as bf16, [k16][lane][8]
 #define RING_MAX_LAYERS 10                             // trunk depth the LDS bias table is sized for
@@ -528,6 +552,9 @@ __global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const F
 #pragma unroll
   for (int g = 0; g < RingCfg<NW>::LEAD; ++g) ring_issue<NW>(r);
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RingCfg<NW>::PPW * (RingCfg<NW>::LEAD - 1)) : "memory");
+#ifdef RSN_RING_SETPRIO
+  if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);  // the younger half of the workgroup loses every arbitration otherwise
+#endif
   bf16x8 Wf[RING_FIFO];
 #pragma unroll
   for (int j = 0; j < RING_FIFO; ++j) Wf[j] = *reinterpret_cast<const bf16x8*>(smem + r.rd_next + j * 1024);
@@ -594,8 +621,13 @@ __global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const F
         const float ang = sx * f;
         // exp by v_exp_f32 (2^x): ~1e-6 relative on a feature that is rounded to bf16 (2^-9) next
         const float e = has_cov ? __builtin_amdgcn_exp2f((-0.5f * (v * (f * f))) * 1.4426950408889634f) : 1.0f;
+#ifndef RSN_RING_EXACT_MATH
+        const float fs = e * sincos_bf16(ang, 0);
+        const float fc = e * sincos_bf16(ang + 1.5707963267948966f, 0);
+#else
         const float fs = e * sin_big(ang);
         const float fc = e * sin_big(ang + 1.5707963267948966f);
+#endif
         const int u = c * 8 + jj, u2 = u + 24;
         STs[(u >> 3) * 512 + ((u >> 2) & 1) * 4 + (u & 3)] = (__bf16)fs;
         STs[(u2 >> 3) * 512 + ((u2 >> 2) & 1) * 4 + (u2 & 3)] = (__bf16)fc;
@@ -652,9 +684,15 @@ __global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const F
       const float r4 = acch[0][4], r5 = acch[0][5], r6 = acch[0][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
       const float rough_raw = __shfl(r4, m, 64);
+#ifndef RSN_RING_EXACT_MATH
+      rho = fast_softplus(rough_raw);
+      dcol[0] = fast_sigmoid(r0); dcol[1] = fast_sigmoid(r1); dcol[2] = fast_sigmoid(r2);
+      tcol[0] = fast_sigmoid(r4); tcol[1] = fast_sigmoid(r5); tcol[2] = fast_sigmoid(r6);
+#else
       rho = softplus_f(rough_raw);
       dcol[0] = sigmoid_f(r0); dcol[1] = sigmoid_f(r1); dcol[2] = sigmoid_f(r2);
       tcol[0] = sigmoid_f(r4); tcol[1] = sigmoid_f(r5); tcol[2] = sigmoid_f(r6);
+#endif
       if (a.mode != RSN_MODE_INF && valid) {
         if (h == 0) {
           float nrm = fmaxf(sqrtf(r1 * r1 + r2 * r2 + r3 * r3), 1e-12f);
