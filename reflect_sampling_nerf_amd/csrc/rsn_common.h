@@ -65,7 +65,11 @@ struct RsnPackedLayout {
   // linear stream in the exact order rsn_field_bf16_ring_kernel consumes them, in groups of 8 fragments (8 KiB): the
   // kernel's workgroups pull it through an LDS ring by LDS-DMA (rsn_field_bf16.hip)
   size_t r_stream;                    // 0 = absent
-  int r_groups;                       // 8-fragment groups per pass over the network
+  int r_groups;                       // fragment groups per pass over the network
+  // the same network as 16x32 fragments for v_mfma_f32_16x16x32_bf16 (rsn_field_bf16_ring16_kernel): lane
+  // (i = lane & 15, g = lane >> 4) holds W[16 b + i][feature(kk, g, e)], e = 0..7, of fragment (K-step kk, row block b)
+  size_t q_stream;                    // 0 = absent
+  int q_groups;
   size_t total;                       // floats
 };
 #ifndef RSN_RING_GROUP_FRAGS

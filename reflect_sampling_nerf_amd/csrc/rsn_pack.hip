@@ -136,6 +136,11 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
     L->r_groups = (enc_ks * 8 * (d->skip_layer >= 1 ? 2 : 1) + (d->num_layers - 1) * 128 + 16 + 128 + 16 + 64 + rgb_ks) / G;
     L->r_stream = off;
     off += (size_t)L->r_groups * RSN_RING_GROUP_FRAGS * blk;
+    if (G == 16) {  // 16x32 fragments: enc 4 x 16, x 8 x 16, heads 8 x 2, bottleneck 8 x 16, mid SH 2 x 8, mid x 8 x 8, rgb 4 x 4
+      L->q_groups = (64 * (d->skip_layer >= 1 ? 2 : 1) + (d->num_layers - 1) * 128 + 16 + 128 + 16 + 64 + 16) / 16;
+      L->q_stream = off;
+      off += (size_t)L->q_groups * 16 * blk;
+    }
   }
   L->total = off;
   return RSN_OK;
@@ -157,6 +162,7 @@ struct PackJob {
   int ld[PACK_MAX_SRC];
   float* dst;
   int n_it, nbo, is_bias, n_rows, transpose;  // transpose: packed row n <- source COLUMN, packed k <- source ROW
+  int layout;  // 0: fp32 [it][nb][lane][4] (32x32x2 fragments);  1: bf16 [k32][b16][lane][8] (16x16x32 fragments)
   int16_t row_src[PACK_MAX_ROWS];  // which src a packed row comes from, -1 = zero row
   int16_t row_idx[PACK_MAX_ROWS];  // row inside that src
   int16_t col[PACK_MAX_COLS];      // source column of packed k, -1 = zero
@@ -164,6 +170,17 @@ struct PackJob {
 };
 
 __device__ __forceinline__ void pack_elem(const PackJob& job, int e) {
+  if (job.layout == 1) {  // one bf16 of a 16x32 fragment: row 16 b + (lane & 15), k = 32 kk + 8 (lane >> 4) + el
+    if (e >= job.n_it * job.nbo * 512) return;
+    const int el = e & 7, lane = (e >> 3) & 63, frag = e >> 9;
+    const int b = frag % job.nbo, kk = frag / job.nbo;
+    const int n = b * 16 + (lane & 15), k = kk * 32 + (lane >> 4) * 8 + el;
+    const int rs = job.row_src[n], c = job.col[k];
+    float v = 0.0f;
+    if (rs >= 0 && c >= 0) v = job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
+    reinterpret_cast<__bf16*>(job.dst)[e] = (__bf16)v;
+    return;
+  }
   if (job.is_bias) {
     if (e < job.n_rows) {
       const int rs = job.row_src[e];
@@ -199,7 +216,7 @@ __global__ void rsn_pack_kernel(const PackJob job) { pack_elem(job, blockIdx.x *
 
 // Every segment in ONE launch (rsn_pack_weights_table): the job descriptors live in device memory, uploaded once per
 // (parameter pointers, shape); workgroup b serves job j with block_start[j] <= b < block_start[j + 1].
-#define PACK_MAX_JOBS 64
+#define PACK_MAX_JOBS 96
 struct PackTable {
   int n_jobs, n_blocks;
   int block_start[PACK_MAX_JOBS + 1];
@@ -371,7 +388,7 @@ int launch(const PackJob& j, hipStream_t st) {
     g_collect->jobs.push_back(j);
     return RSN_OK;
   }
-  const int total = j.is_bias ? j.n_rows : j.n_it * j.nbo * 256;
+  const int total = j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout == 1 ? 512 : 256);
   const int threads = 256;
   hipLaunchKernelGGL(rsn_pack_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, j);
   RSN_HIP(hipGetLastError());
@@ -539,6 +556,78 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   rows_natural(j, W);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
 
+  // ---------------- 16x32 bf16 fragment stream (rsn_field_bf16_ring16_kernel), straight from the nn.Linear tensors ------
+  if (L.q_stream != 0) {
+    int frag = 0;
+    // K order of an x-layer: slot (kk, g, e) <- previous layer's feature 32 kk + 16 (e / 4) + 4 g + e % 4: the eight
+    // values lane (m, g) holds of blocks 2kk, 2kk+1 after the previous GEMM (lane-local hand-off)
+    auto cols_x16 = [&](PackJob& jj, int K, int offset) {
+      for (int k = 0; k < K; ++k) {
+        const int kk = k >> 5, g = (k >> 3) & 3, e = k & 7;
+        jj.col[k] = (int16_t)(offset + 32 * kk + 16 * (e >> 2) + 4 * g + (e & 3));
+      }
+    };
+    // encoded inputs: lane group g owns frequencies 4g..4g+3; its 32 slots u = 8 kk + e: 12 sin, 12 cos, 3 raw (g == 0)
+    auto cols_enc16 = [&](PackJob& jj) {
+      for (int k = 0; k < 128; ++k) {
+        const int kk = k >> 5, g = (k >> 3) & 3, e = k & 7, u = kk * 8 + e;
+        int c = -1;
+        if (u < 12) c = (u / 4) * 16 + 4 * g + (u % 4);
+        else if (u < 24) c = 48 + ((u - 12) / 4) * 16 + 4 * g + ((u - 12) % 4);
+        else if (u < 27 && g == 0) c = 96 + (u - 24);
+        jj.col[k] = (int16_t)c;
+      }
+    };
+    // SH inputs: lane group g owns components 9g .. 9g+8 (7 for g == 3) in its slots u = 8 kk + e < 9
+    auto cols_sh16 = [&](PackJob& jj) {
+      for (int k = 0; k < 64; ++k) {
+        const int kk = k >> 5, g = (k >> 3) & 3, e = k & 7, u = kk * 8 + e;
+        jj.col[k] = (int16_t)((u < 9 && 9 * g + u < RSN_SH_DIM) ? 9 * g + u : -1);
+      }
+    };
+    auto qpiece = [&](PackJob& jj, int ks, int nbo16) -> int {
+      jj.layout = 1; jj.n_it = ks; jj.nbo = nbo16;
+      jj.dst = packed + L.q_stream + (size_t)frag * 256;
+      frag += ks * nbo16;
+      return launch(jj, st);
+    };
+    clear_job(j);
+    j.src[0] = p->trunk_w[0]; j.ld[0] = RSN_ENC_DIM; rows_natural(j, W); cols_enc16(j);
+    if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
+    for (int l = 1; l < d->num_layers; ++l) {
+      const int in_f = (l == d->skip_layer) ? RSN_ENC_DIM + W : W;
+      clear_job(j);
+      j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_natural(j, W); cols_x16(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0);
+      if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
+      if (l == d->skip_layer) {
+        clear_job(j);
+        j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_natural(j, W); cols_enc16(j);
+        if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
+      }
+    }
+    clear_job(j);  // heads: ONE 16-row block (0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint) + a zero block
+    j.src[1] = p->density_w; j.src[2] = p->normals_w; j.src[3] = p->diff_w; j.src[4] = p->roughness_w; j.src[5] = p->tint_w;
+    for (int i = 0; i < PACK_MAX_SRC; ++i) j.ld[i] = W;
+    heads_rows(j, 0); cols_x16(j, W, 0);
+    if ((rc = qpiece(j, 8, 2)) != RSN_OK) return rc;
+    clear_job(j);
+    j.src[0] = p->bottleneck_w; j.ld[0] = W; rows_natural(j, W); cols_x16(j, W, 0);
+    if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
+    clear_job(j);
+    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_natural(j, d->mid_width); cols_sh16(j);
+    if ((rc = qpiece(j, 2, 8)) != RSN_OK) return rc;
+    clear_job(j);
+    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_natural(j, d->mid_width); cols_x16(j, W, RSN_SH_DIM);
+    if ((rc = qpiece(j, 8, 8)) != RSN_OK) return rc;
+    clear_job(j);  // RGB head: rows 4..6 of the first of four 16-row blocks (three of them zero: whole-group padding)
+    j.src[0] = p->rgb_w; j.ld[0] = d->mid_width;
+    for (int c = 0; c < 3; ++c) { j.row_src[4 + c] = 0; j.row_idx[4 + c] = (int16_t)c; }
+    cols_x16(j, d->mid_width, 0);
+    if ((rc = qpiece(j, 4, 4)) != RSN_OK) return rc;
+    RSN_REQUIRE(frag == L.q_groups * 16, RSN_ERR_INVALID_ARGUMENT, "16x32 stream: %d fragments, layout says %d groups",
+                frag, L.q_groups);
+  }
+
   // ---------------- split-bf16 copies (RSN_MMA_BF16X6 / X3 / BF16) of every GEMM segment ----------------
   if (d->mma_mode == RSN_MMA_F32) return RSN_OK;  // the exact-fp32 kernels never read them
   if ((rc = split_seg(packed + L.w_enc0, RSN_ENC_ITS, NB, packed + L.h_enc0, st)) != RSN_OK) return rc;
@@ -626,13 +715,14 @@ extern "C" int rsn_pack_weights_table(const rsn_field_desc* d, const rsn_field_p
       const PackJob& j = col.jobs[i];
       host_table.block_start[i] = blocks;
       host_table.jobs[i] = j;
-      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * 256) + 255) / 256;
+      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout == 1 ? 512 : 256)) + 255) / 256;
     }
     host_table.block_start[host_table.n_jobs] = blocks;
     host_table.n_blocks = blocks;
     RSN_HIP(hipMemcpyAsync(table, &host_table, sizeof(PackTable), hipMemcpyHostToDevice, st));
   } else {
-    for (const PackJob& j : col.jobs) blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * 256) + 255) / 256;
+    for (const PackJob& j : col.jobs)
+      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout == 1 ? 512 : 256)) + 255) / 256;
   }
   hipLaunchKernelGGL(rsn_pack_all_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const PackTable*)table);
   RSN_HIP(hipGetLastError());
