@@ -353,7 +353,7 @@ def run_level(pkg, args, dev, steps, warmup, dog):
     flop = 2.0 * macs["forward"] * R * S
     achieved = flop / (kms * 1e-3) / 1e12
     mode_idx = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "bf16": 3}[args.mma]
-    kname = ("rsn_field_bf16_ring_kernel" if args.width == 256 else "rsn_field_bf16_kernel<%d>" % (args.width // 32)) \
+    kname = ("rsn_field_bf16_ring16_kernel" if args.width == 256 else "rsn_field_bf16_kernel<%d>" % (args.width // 32)) \
         if args.mma == "bf16" else \
         "rsn_field_kernel<%d, false, %d>" % (args.width // 32, mode_idx)
     # f32: algorithmic FLOP against the fp32-MFMA peak.  Split modes issue 6 (3) bf16 MFMA FLOP per algorithmic FLOP:
