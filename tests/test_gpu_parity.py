@@ -561,6 +561,51 @@ def test_get_outputs_bf16x6_meets_fp32_tolerance(dev):
     assert torch.equal(out["mask"].cpu(), ref["mask"])
 
 
+def test_get_outputs_bf16_ring_kernel_all_modes(dev):
+    """The bf16 ring kernel (width 256) behind a whole eval get_outputs: frustum levels, the reflected levels with
+    the device-side ray count (n_dev), get_inf_color (no view-direction inputs), ragged tiles (R = 70, 333 rays: last
+    256-point tile partly empty) -- against the oracle within the bf16 tolerance, and the Gaussian / embedding entry
+    against the exact-fp32 kernel."""
+    for R, seed in ((70, 62), (333, 63)):
+        torch.manual_seed(12)
+        cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=32, num_importance_samples=24,
+                                                num_reflect_coarse_samples=16, num_reflect_importance_samples=8,
+                                                base_mlp_num_layers=8, base_mlp_layer_width=256)
+        model = cfg.setup(scene_box=None, num_train_data=1)
+        with torch.no_grad():
+            model.field.field_output_density.net.bias += 2.0
+        P = {k: v.detach().clone() for k, v in model.field.state_dict().items()}
+        model.to(dev).eval()
+        model.field.set_mma_mode("bf16")
+        o, d, pa = cpu_ref.synthetic_rays(R, seed=seed)
+        nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+        rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev), nears=nears.to(dev),
+                           fars=fars.to(dev))
+        out = model(rb)
+        with torch.no_grad():
+            ref = cpu_ref.get_outputs(P, cpu_ref.FieldSpec(), cpu_ref.ModelSpec(32, 24, 16, 8), o, d, pa, nears, fars)
+        assert int(ref["mask"].sum()) > 0
+        same = out["mask"].cpu() == ref["mask"]
+        assert float(same.float().mean()) >= 0.97  # a ray on the mask threshold may flip at bf16 precision
+        for k in ("mid_rgb_coarse", "mid_rgb_fine", "accumulation_coarse", "accumulation_fine", "diff", "tint", "roughness"):
+            assert bool(torch.isfinite(out[k]).all()), k
+            assert max_abs(out[k].cpu(), ref[k]) <= 3e-2, k
+        for k in ("mid_reflect_coarse", "mid_reflect_fine"):  # on the rays both pipelines reflect (or both do not)
+            assert max_abs(out[k].cpu()[same], ref[k][same]) <= 5e-2, k
+    # explicit Gaussians + embedding output through the ring kernel vs the exact-fp32 kernel
+    fld = model.field
+    g = torch.Generator().manual_seed(4)
+    means = (torch.randn(300, 3, generator=g) * 0.8).to(dev)
+    covd = (torch.rand(300, 3, generator=g) * 1e-4).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1).to(dev)
+    lb = fld.evaluate_gaussians(means, covd, dirs, want_embedding=True)
+    fld.set_mma_mode("f32")
+    lf = fld.evaluate_gaussians(means, covd, dirs, want_embedding=True)
+    assert max_abs(lb["color"], lf["color"]) <= 3e-2 and max_abs(lb["pred_normals"], lf["pred_normals"]) <= 5e-2
+    assert float(((lb["embedding"] - lf["embedding"]).abs() / (1.0 + lf["embedding"].abs())).max()) <= 3e-2
+    assert float(((lb["sigma"] - lf["sigma"]).abs() / (1.0 + lf["sigma"].abs())).max()) <= 3e-2
+
+
 # ---------------------------------------------------------------------------------------------- granular Field API
 def test_granular_field_api(dev):
     """The Field methods the reference Model calls one by one: get_blob, contract, get_density,
