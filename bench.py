@@ -492,7 +492,7 @@ def main():
                 line["train_step_bf16_sweeps"] = {
                     "workload": "the headline step in REDUCED precision (opt-in; the reference itself trains under fp16 "
                                 "autocast, config.py:33): forward / backward sweeps with plain bf16 MFMA operands and fp32 "
-                                "accumulation, weight gradients exact fp32 over fp32-saved activations",
+                                "accumulation, weight-gradient operands rounded to bf16 in-kernel (fp32-saved activations, fp32 accumulation)",
                     **{k: bf[k] for k in ("value", "unit", "ms_per_step", "steps")}}
                 line["train_step_bf16x6_sweeps"] = {
                     "workload": "the headline step with the forward / backward sweeps on split-bf16 MFMA (3-way split, 6 "

@@ -41,8 +41,12 @@ struct WGradArgs {
 // NKB: input-column blocks of 32 held per wave (8 covers k_in <= 256).
 // XV: lane i owns columns i*NKB.. (vector loads of X);  else column kb*32+i (scalar loads, any k_in / alignment).
 // DV: lane i owns rows 2i, 2i+1 of the wave's 64 (dwordx2 loads of dY); else rows t*32+i.
-template <int NKB, bool XV, bool DV>
+// BF: reduced-precision variant (opt-in bf16 training mode): the same fp32 row-major operands, rounded to bf16 as they
+// are packed into v_mfma_f32_32x32x16_bf16 fragments (fp32 accumulation, fp32 bias sums); a stage is 16 points, lane
+// half h takes points 8h..8h+7 of it (the K index of the MFMA is the point).
+template <int NKB, bool XV, bool DV, bool BF = false>
 __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
+  constexpr int NP = BF ? 8 : WG_PAIRS;  // points per lane and stage
   __shared__ float tr[4][2][NKB * 32];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar loop control
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     }
   }
 
-  float fa[2][WG_PAIRS][2], fb[2][WG_PAIRS][NKB];  // [buffer][pair][block]
+  float fa[2][NP][2], fb[2][NP][NKB];  // [buffer][point of this lane][block]
+  auto roff = [&](int p) { return BF ? 8 * h + p : 2 * p + h; };  // row of the stage this lane's p-th point is
   const float* __restrict__ dyp = nullptr;
   const float* __restrict__ xp = nullptr;
 
@@ -143,6 +148,28 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     }
   };
   auto mma_stage = [&](int buf) {
+    if (BF) {
+      bf16x8 av[2], bv[NKB];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          bsum[t] += fa[buf][p][t];
+          av[t][p] = (__bf16)fa[buf][p][t];
+        }
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bv[kb][p] = (__bf16)fb[buf][p][kb];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !t1_live) continue;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+          acc[t][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t], bv[kb], acc[t][kb], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < WG_PAIRS; ++p) {
 #pragma unroll
@@ -158,13 +185,13 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
 
   auto interleave_stage = [&]() {
 #pragma unroll
-    for (int g = 0; g < WG_PAIRS * 4; ++g) {
+    for (int g = 0; g < (BF ? 16 : WG_PAIRS * 4); ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
       __builtin_amdgcn_sched_group_barrier(0x026, 2, 0);  // up to 2 of VALU / SALU / VMEM read
     }
   };
 
-  const long long step = 2 * WG_PAIRS;
+  const long long step = 2 * NP;
   long long vprefix = 0;  // stages (full and tail) of the segments in front of this one
   bool any = false;
 #pragma unroll 1
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     if (cnt > 0) {
       any = true;
 #pragma unroll
-      for (int p = 0; p < WG_PAIRS; ++p) load_row(0, p, first * step + 2 * p + h, true);
+      for (int p = 0; p < NP; ++p) load_row(0, p, first * step + roff(p), true);
     }
     long long j = 0;
 #pragma unroll 1
@@ -190,13 +217,13 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
       // block between two MFMA bursts they left the matrix pipe idle for ~10 % of the loop.  Straight-line body
       // (the prefetch index is clamped, not branched on) so that the scheduler can interleave.
 #pragma unroll
-      for (int p = 0; p < WG_PAIRS; ++p) load_row(1, p, m0 + gs + 2 * p + h, true);
+      for (int p = 0; p < NP; ++p) load_row(1, p, m0 + gs + roff(p), true);
       mma_stage(0);
       interleave_stage();
       __builtin_amdgcn_sched_barrier(0);
       const long long m2 = (j + 2 < cnt) ? m0 + 2 * gs : m0 + gs;
 #pragma unroll
-      for (int p = 0; p < WG_PAIRS; ++p) load_row(0, p, m2 + 2 * p + h, true);
+      for (int p = 0; p < NP; ++p) load_row(0, p, m2 + roff(p), true);
       mma_stage(1);
       interleave_stage();
       __builtin_amdgcn_sched_barrier(0);
@@ -205,8 +232,8 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     if (rem > 0 && (vprefix + n_full) % G == g) {  // the segment's tail stage: points beyond n_s contribute zeros
       any = true;
 #pragma unroll
-      for (int p = 0; p < WG_PAIRS; ++p) {
-        const long long m = n_full * step + 2 * p + h;
+      for (int p = 0; p < NP; ++p) {
+        const long long m = n_full * step + roff(p);
         const bool in = m < n_s;
         load_row(0, p, in ? m : 0, in);
       }
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   }
 }
 
-static int wgrad_launch(WGradArgs& a, void* stream) {
+static int wgrad_launch(WGradArgs& a, void* stream, bool bf16 = false) {
   const long long total = a.seg_begin[a.n_seg];
   if (total == 0) return RSN_OK;
   static int cached_cus = 0;
@@ -265,21 +292,7 @@ static int wgrad_launch(WGradArgs& a, void* stream) {
   }
   // grid: every workgroup pays one atomic flush of the output tile (chip-wide ~1.3 TB/s of added bytes) and the
   // waves share the stages; T(G) = stages / (G * nsub) * t_stage + G * t_flush is smallest at G = sqrt(...)
-  const int nkb_ = a.k_in > 128 ? 8 : (a.k_in > 64 ? 4 : 2);
-  const int P = a.n_out <= 64 ? 1 : (a.n_out <= 128 ? 2 : 4);
-  const int nsub = 4 / P;
-  long long stages = 0;
-  for (int s = 0; s < a.n_seg; ++s) {
-    const long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
-    stages += (n_s + 2 * WG_PAIRS - 1) / (2 * WG_PAIRS);
-  }
-  const double t_stage = WG_PAIRS * (a.n_out > 32 ? 2 : 1) * nkb_ * 64 / 2.1e9;
-  const double t_flush = (double)a.n_out * a.k_in * 4.0 / 1.3e12 + 2e-8;
-  long long grid = (long long)(sqrt((double)stages * t_stage / (nsub * t_flush)) + 0.5);
-  if (grid > cached_cus) grid = cached_cus;
-  if (grid < 1) grid = 1;
-  hipStream_t st = (hipStream_t)stream;
-  const int nkb = a.k_in > 128 ? 8 : (a.k_in > 64 ? 4 : 2);
+  const int nkb = a.k_in > 128 ? 8 : (a.k_in > 64 ? 4 : 2), nkb_ = nkb;
   // vector-load variants need whole NKB-column groups and aligned rows; anything else takes the scalar-load path
   bool xv = a.k_in % nkb == 0 && a.ld_x % (nkb >= 4 ? 4 : 2) == 0;
   bool dv = a.n_out > 32 && a.ld_dy % 2 == 0 && a.ld_dy >= a.n_out + (a.n_out & 1);
@@ -287,9 +300,27 @@ static int wgrad_launch(WGradArgs& a, void* stream) {
     xv = xv && ((uintptr_t)a.x[s] % 16 == 0);
     dv = dv && ((uintptr_t)a.dy[s] % 8 == 0);
   }
+  bf16 = bf16 && xv && dv;  // the bf16 variant exists for the vector-load layout only
+  const int P = a.n_out <= 64 ? 1 : (a.n_out <= 128 ? 2 : 4);
+  const int nsub = 4 / P;
+  long long stages = 0;
+  const int stage_pts = bf16 ? 16 : 2 * WG_PAIRS;
+  for (int s = 0; s < a.n_seg; ++s) {
+    const long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
+    stages += (n_s + stage_pts - 1) / stage_pts;
+  }
+  const double t_stage = bf16 ? (a.n_out > 32 ? 2 : 1) * nkb_ * 32 / 1.9e9 * 2.5  // HBM-bound in practice: ~2.5x the MFMA time
+                              : WG_PAIRS * (a.n_out > 32 ? 2 : 1) * nkb_ * 64 / 2.1e9;
+  const double t_flush = (double)a.n_out * a.k_in * 4.0 / 1.3e12 + 2e-8;
+  long long grid = (long long)(sqrt((double)stages * t_stage / (nsub * t_flush)) + 0.5);
+  if (grid > cached_cus) grid = cached_cus;
+  if (grid < 1) grid = 1;
+  hipStream_t st = (hipStream_t)stream;
 #define RSN_WG(NKBV)                                                                                           \
   do {                                                                                                         \
-    if (xv && dv)                                                                                              \
+    if (xv && dv && bf16)                                                                                      \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+    else if (xv && dv)                                                                                         \
       hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a);     \
     else if (xv)                                                                                               \
       hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, false>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
@@ -307,9 +338,19 @@ static int wgrad_launch(WGradArgs& a, void* stream) {
   return RSN_OK;
 }
 
+static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
+                                  int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
+                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, bool bf16);
+
 extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                      int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
                                      const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream) {
+  return weight_grad_multi_impl(n_segments, n_points, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream, false);
+}
+
+static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
+                                  int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
+                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, bool bf16) {
   RSN_REQUIRE(n_segments >= 0 && n_segments <= WG_MAX_SEG, RSN_ERR_INVALID_ARGUMENT, "n_segments=%d (at most %d)",
               n_segments, WG_MAX_SEG);
   RSN_REQUIRE(n_out >= 1 && n_out <= 256 && k_in >= 1 && k_in <= 256, RSN_ERR_INVALID_ARGUMENT,
@@ -332,7 +373,13 @@ extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points
   a.n_seg = ns;
   a.ld_dy = ld_dy; a.ld_x = ld_x; a.n_out = n_out; a.k_in = k_in;
   a.ld_dw = ld_dw; a.col_map = col_map; a.dw = dw; a.db = db;
-  return wgrad_launch(a, stream);
+  return wgrad_launch(a, stream, bf16);
+}
+
+extern "C" int rsn_weight_grad_multi_bf16(int32_t n_segments, const int64_t* n_points, const float* const* dy,
+                                          int32_t ld_dy, int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
+                                          const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream) {
+  return weight_grad_multi_impl(n_segments, n_points, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream, true);
 }
 
 extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x,

@@ -142,6 +142,9 @@ def _wgrad(dy: Tensor, n_out: int, x: Tensor, k_in: int, dw: Tensor, dw_col0: in
     _wgrad_multi([(dy, x)], n_out, k_in, dw, dw_col0, db, col_map)
 
 
+_WGRAD_BF16 = False  # set per step by _weight_grads: the Field's opt-in bf16 training mode
+
+
 def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Optional[Tensor],
                  col_map: Optional[Tensor] = None):
     """One rsn_weight_grad_multi launch: the reduction runs over the points of every (dy, x) segment (the field
@@ -158,13 +161,15 @@ def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Opti
     xs = (C.c_void_p * ns)(*[x.data_ptr() for _, x in segs])
     dwp = C.c_void_p(dw.data_ptr() + 4 * dw_col0)
     ops.timed("weight_grad", {"point_out_in": sum(dy.shape[0] for dy, _ in segs) * n_out * k_in},
-              lambda: check(lib.rsn_weight_grad_multi(ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp,
-                                                      dw.stride(0), ptr(db), ops._stream())))
+              lambda: check((lib.rsn_weight_grad_multi_bf16 if _WGRAD_BF16 else lib.rsn_weight_grad_multi)(
+                  ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp, dw.stride(0), ptr(db), ops._stream())))
 
 
 def _weight_grads(field, levels, acc: _GradAcc):
     """dW = dY^T X (+ db) for every linear layer, reduced over all field evaluations of the step at once.
     levels: list of (saved activations, backward-sweep outputs, with_heads)."""
+    global _WGRAD_BF16
+    _WGRAD_BF16 = int(field.mma_mode) == _abi.RSN_MMA_BF16  # reduced-precision training: bf16 operands in the reduction too
     L, W = field.mlp_base.num_layers, field.width
     skip = field.field_desc().skip_layer
     enc_map, sh_map = field._enc_col_map, field._sh_col_map

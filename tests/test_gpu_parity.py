@@ -904,6 +904,35 @@ def test_weight_grad_segments_and_shapes(dev, n_out, k_in, ld_dy, ld_x):
     assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
 
 
+@pytest.mark.parametrize("n_out,k_in", [(256, 256), (256, 104), (128, 40), (16, 256), (250, 99)])
+def test_weight_grad_bf16_variant(dev, monkeypatch, n_out, k_in):
+    """rsn_weight_grad_multi_bf16 (the opt-in bf16 training mode's reduction): operands rounded to bf16 inside the kernel,
+    fp32 accumulation -> equals the fp64 product of the bf16-ROUNDED operands to fp32 accumulation accuracy, the bias sums
+    stay exact-fp32, and shapes its vector loads cannot take fall back to the exact kernel."""
+    from reflect_sampling_nerf_amd import train_graph
+
+    g = torch.Generator().manual_seed(n_out + k_in)
+    lens = [1000, 0, 37, 5003, 3]
+    segs = []
+    ref_w, ref_b = torch.zeros(n_out, k_in, dtype=torch.float64), torch.zeros(n_out, dtype=torch.float64)
+    exact_w = torch.zeros(n_out, k_in, dtype=torch.float64)
+    for n in lens:
+        dy, x = torch.randn(n, n_out, generator=g), torch.randn(n, k_in, generator=g)
+        ref_w += dy.bfloat16().double().t() @ x.bfloat16().double()
+        exact_w += dy.double().t() @ x.double()
+        ref_b += dy.double().sum(0)
+        segs.append((dy.to(dev), x.to(dev)))
+    dw, db = torch.zeros(n_out, k_in, device=dev), torch.zeros(n_out, device=dev)
+    monkeypatch.setattr(train_graph, "_WGRAD_BF16", True)
+    train_graph._wgrad_multi(segs, n_out, k_in, dw, 0, db)
+    got = dw.double().cpu()
+    vector_path = n_out > 32 and k_in % (8 if k_in > 128 else 4 if k_in > 64 else 2) == 0
+    target = ref_w if vector_path else exact_w
+    assert float((got - target).abs().max()) <= 2e-5 * float(target.abs().max())
+    assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+    assert float((got - exact_w).abs().max()) <= 2e-2 * float(exact_w.abs().max())  # bf16 rounding of both operands
+
+
 def test_standalone_sh34_encoding_matches_reference_golden(dev):
     """IntegratedSHEncoding called as a module (rsn_sh34_encode) against the output of the reference's own
     IntegratedSHEncoding.forward (tests/golden/units.npz, oracle/make_golden.py) and against the oracle."""
