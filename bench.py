@@ -496,7 +496,7 @@ def main():
                     **{k: bf[k] for k in ("value", "unit", "ms_per_step", "steps")}}
                 line["train_step_bf16x6_sweeps"] = {
                     "workload": "the headline step with the forward / backward sweeps on split-bf16 MFMA (3-way split, 6 "
-                                "products, fp32 accumulate: fp32-equivalent, opt-in); weight gradients stay exact fp32",
+                                "products, fp32 accumulate: fp32-equivalent, opt-in); weight-gradient operands split the same way in-kernel",
                     **{k: x6[k] for k in ("value", "unit", "ms_per_step", "steps")}}
                 line["train_step_configs2"] = {
                     "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect 64 + 64, forward + backward "

@@ -333,12 +333,16 @@ int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const flo
                           int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map,
                           float* dw, int32_t ld_dw, float* db, void* stream);
 
-/* Reduced-precision variant for the opt-in bf16 training mode (rsn_field_desc.mma_mode == RSN_MMA_BF16): the same
- * fp32 buffers, operands rounded to bf16 inside the kernel, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 bias
- * sums.  Falls back to the exact kernel for shapes / alignments its vector loads do not cover. */
-int rsn_weight_grad_multi_bf16(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
+/* The same reduction in the Field's MMA mode (rsn_field_desc.mma_mode), over the same fp32 buffers:
+ *   RSN_MMA_F32 / RSN_MMA_BF16X3  the exact kernel above;
+ *   RSN_MMA_BF16X6  both operands split exactly into bf16 triples inside the kernel, 6 products on
+ *                   v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-equivalent (dropped terms <= 2^-24 relative);
+ *   RSN_MMA_BF16    operands rounded to bf16 (the opt-in reduced-precision training mode), fp32 accumulation.
+ * Bias sums are exact fp32 in every mode.  Shapes / alignments the vector-load layout does not cover take the exact
+ * kernel. */
+int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map,
-                               float* dw, int32_t ld_dw, float* db, void* stream);
+                               float* dw, int32_t ld_dw, float* db, int32_t mma_mode, void* stream);
 
 /* rsn_colsum: out[c] (+)= sum_r x[r*ld + c], c < n_cols (bias gradients = column sums of dY). */
 int rsn_colsum(int64_t n_rows, int32_t n_cols, int32_t ld, const float* x, float* out, int32_t accumulate,

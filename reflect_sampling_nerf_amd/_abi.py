@@ -117,9 +117,9 @@ _SIGNATURES = {
     "rsn_weight_grad_multi": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                         C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _fp, C.c_void_p, C.c_int32, _fp,
                                         C.c_void_p]),
-    "rsn_weight_grad_multi_bf16": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
+    "rsn_weight_grad_multi_mode": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                              C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _fp, C.c_void_p, C.c_int32, _fp,
-                                             C.c_void_p]),
+                                             C.c_int32, C.c_void_p]),
     "rsn_loss_forward_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp),
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_float), _fp,
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.c_void_p]),

@@ -41,10 +41,12 @@ struct WGradArgs {
 // NKB: input-column blocks of 32 held per wave (8 covers k_in <= 256).
 // XV: lane i owns columns i*NKB.. (vector loads of X);  else column kb*32+i (scalar loads, any k_in / alignment).
 // DV: lane i owns rows 2i, 2i+1 of the wave's 64 (dwordx2 loads of dY); else rows t*32+i.
-// BF: reduced-precision variant (opt-in bf16 training mode): the same fp32 row-major operands, rounded to bf16 as they
-// are packed into v_mfma_f32_32x32x16_bf16 fragments (fp32 accumulation, fp32 bias sums); a stage is 16 points, lane
-// half h takes points 8h..8h+7 of it (the K index of the MFMA is the point).
-template <int NKB, bool XV, bool DV, bool BF = false>
+// BF != 0: the same reduction on v_mfma_f32_32x32x16_bf16 over the same fp32 row-major operands (fp32 accumulation, fp32
+// bias sums); a stage is 16 points, lane half h takes points 8h..8h+7 of it (the K index of the MFMA is the point).
+//   BF = 3 (RSN_MMA_BF16X6): both operands split exactly into bf16 triples as they are packed, the 6 leading products
+//          (dropped terms <= 2^-24 relative): fp32-equivalent at 2.7x the fp32 MFMA rate;
+//   BF = 1 (RSN_MMA_BF16, the opt-in reduced-precision training mode): operands rounded to bf16, one product.
+template <int NKB, bool XV, bool DV, int BF = 0>
 __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   constexpr int NP = BF ? 8 : WG_PAIRS;  // points per lane and stage
   __shared__ float tr[4][2][NKB * 32];
@@ -148,6 +150,49 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     }
   };
   auto mma_stage = [&](int buf) {
+    if (BF == 3) {
+      bf16x8 a1[2], a2[2], a3[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const float x = fa[buf][p][t];
+          bsum[t] += x;
+          const __bf16 s1 = (__bf16)x;
+          const float r1 = x - (float)s1;
+          const __bf16 s2 = (__bf16)r1;
+          a1[t][p] = s1;
+          a2[t][p] = s2;
+          a3[t][p] = (__bf16)(r1 - (float)s2);
+        }
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        bf16x8 b1, b2, b3;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const float x = fb[buf][p][kb];
+          const __bf16 s1 = (__bf16)x;
+          const float r1 = x - (float)s1;
+          const __bf16 s2 = (__bf16)r1;
+          b1[p] = s1;
+          b2[p] = s2;
+          b3[p] = (__bf16)(r1 - (float)s2);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t == 1 && !t1_live) continue;
+          f32x16 c = acc[t][kb];  // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[t], b1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b3, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], b1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b1, c, 0, 0, 0);
+          acc[t][kb] = c;
+        }
+      }
+      return;
+    }
     if (BF) {
       bf16x8 av[2], bv[NKB];
 #pragma unroll
@@ -185,7 +230,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
 
   auto interleave_stage = [&]() {
 #pragma unroll
-    for (int g = 0; g < (BF ? 16 : WG_PAIRS * 4); ++g) {
+    for (int g = 0; g < (BF == 3 ? 96 : (BF ? 16 : WG_PAIRS * 4)); ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
       __builtin_amdgcn_sched_group_barrier(0x026, 2, 0);  // up to 2 of VALU / SALU / VMEM read
     }
@@ -278,7 +323,8 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   }
 }
 
-static int wgrad_launch(WGradArgs& a, void* stream, bool bf16 = false) {
+static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0) {
+  bool bf16 = mode == RSN_MMA_BF16 || mode == RSN_MMA_BF16X6;
   const long long total = a.seg_begin[a.n_seg];
   if (total == 0) return RSN_OK;
   static int cached_cus = 0;
@@ -309,7 +355,7 @@ static int wgrad_launch(WGradArgs& a, void* stream, bool bf16 = false) {
     const long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
     stages += (n_s + stage_pts - 1) / stage_pts;
   }
-  const double t_stage = bf16 ? (a.n_out > 32 ? 2 : 1) * nkb_ * 32 / 1.9e9 * 2.5  // HBM-bound in practice: ~2.5x the MFMA time
+  const double t_stage = bf16 ? (a.n_out > 32 ? 2 : 1) * nkb_ * 32 / 1.9e9 * (mode == RSN_MMA_BF16X6 ? 6 : 2.5)  // 1 product: HBM-bound, ~2.5x the MFMA time
                               : WG_PAIRS * (a.n_out > 32 ? 2 : 1) * nkb_ * 64 / 2.1e9;
   const double t_flush = (double)a.n_out * a.k_in * 4.0 / 1.3e12 + 2e-8;
   long long grid = (long long)(sqrt((double)stages * t_stage / (nsub * t_flush)) + 0.5);
@@ -318,8 +364,10 @@ static int wgrad_launch(WGradArgs& a, void* stream, bool bf16 = false) {
   hipStream_t st = (hipStream_t)stream;
 #define RSN_WG(NKBV)                                                                                           \
   do {                                                                                                         \
-    if (xv && dv && bf16)                                                                                      \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+    if (xv && dv && bf16 && mode == RSN_MMA_BF16X6)                                                            \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);  \
+    else if (xv && dv && bf16)                                                                                 \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);  \
     else if (xv && dv)                                                                                         \
       hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a);     \
     else if (xv)                                                                                               \
@@ -340,17 +388,17 @@ static int wgrad_launch(WGradArgs& a, void* stream, bool bf16 = false) {
 
 static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                   int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
-                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, bool bf16);
+                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode);
 
 extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                      int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
                                      const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream) {
-  return weight_grad_multi_impl(n_segments, n_points, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream, false);
+  return weight_grad_multi_impl(n_segments, n_points, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream, RSN_MMA_F32);
 }
 
 static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                   int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
-                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, bool bf16) {
+                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode) {
   RSN_REQUIRE(n_segments >= 0 && n_segments <= WG_MAX_SEG, RSN_ERR_INVALID_ARGUMENT, "n_segments=%d (at most %d)",
               n_segments, WG_MAX_SEG);
   RSN_REQUIRE(n_out >= 1 && n_out <= 256 && k_in >= 1 && k_in <= 256, RSN_ERR_INVALID_ARGUMENT,
@@ -373,13 +421,16 @@ static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, c
   a.n_seg = ns;
   a.ld_dy = ld_dy; a.ld_x = ld_x; a.n_out = n_out; a.k_in = k_in;
   a.ld_dw = ld_dw; a.col_map = col_map; a.dw = dw; a.db = db;
-  return wgrad_launch(a, stream, bf16);
+  return wgrad_launch(a, stream, mode);
 }
 
-extern "C" int rsn_weight_grad_multi_bf16(int32_t n_segments, const int64_t* n_points, const float* const* dy,
+extern "C" int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_points, const float* const* dy,
                                           int32_t ld_dy, int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
-                                          const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream) {
-  return weight_grad_multi_impl(n_segments, n_points, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream, true);
+                                          const int32_t* col_map, float* dw, int32_t ld_dw, float* db, int32_t mma_mode,
+                                          void* stream) {
+  RSN_REQUIRE(mma_mode >= RSN_MMA_F32 && mma_mode <= RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "mma_mode %d", mma_mode);
+  return weight_grad_multi_impl(n_segments, n_points, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream,
+                                mma_mode);
 }
 
 extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x,

@@ -142,7 +142,7 @@ def _wgrad(dy: Tensor, n_out: int, x: Tensor, k_in: int, dw: Tensor, dw_col0: in
     _wgrad_multi([(dy, x)], n_out, k_in, dw, dw_col0, db, col_map)
 
 
-_WGRAD_BF16 = False  # set per step by _weight_grads: the Field's opt-in bf16 training mode
+_WGRAD_MODE = 0  # RSN_MMA_*: set per step by _weight_grads from the Field's MMA mode
 
 
 def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Optional[Tensor],
@@ -161,15 +161,15 @@ def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Opti
     xs = (C.c_void_p * ns)(*[x.data_ptr() for _, x in segs])
     dwp = C.c_void_p(dw.data_ptr() + 4 * dw_col0)
     ops.timed("weight_grad", {"point_out_in": sum(dy.shape[0] for dy, _ in segs) * n_out * k_in},
-              lambda: check((lib.rsn_weight_grad_multi_bf16 if _WGRAD_BF16 else lib.rsn_weight_grad_multi)(
-                  ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp, dw.stride(0), ptr(db), ops._stream())))
+              lambda: check(lib.rsn_weight_grad_multi_mode(ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp,
+                                                           dw.stride(0), ptr(db), _WGRAD_MODE, ops._stream())))
 
 
 def _weight_grads(field, levels, acc: _GradAcc):
     """dW = dY^T X (+ db) for every linear layer, reduced over all field evaluations of the step at once.
     levels: list of (saved activations, backward-sweep outputs, with_heads)."""
-    global _WGRAD_BF16
-    _WGRAD_BF16 = int(field.mma_mode) == _abi.RSN_MMA_BF16  # reduced-precision training: bf16 operands in the reduction too
+    global _WGRAD_MODE
+    _WGRAD_MODE = int(field.mma_mode)  # bf16x6: split operands (fp32-equivalent); bf16: rounded operands (reduced precision)
     L, W = field.mlp_base.num_layers, field.width
     skip = field.field_desc().skip_layer
     enc_map, sh_map = field._enc_col_map, field._sh_col_map

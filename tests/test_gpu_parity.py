@@ -904,11 +904,13 @@ def test_weight_grad_segments_and_shapes(dev, n_out, k_in, ld_dy, ld_x):
     assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x6"])
 @pytest.mark.parametrize("n_out,k_in", [(256, 256), (256, 104), (128, 40), (16, 256), (250, 99)])
-def test_weight_grad_bf16_variant(dev, monkeypatch, n_out, k_in):
-    """rsn_weight_grad_multi_bf16 (the opt-in bf16 training mode's reduction): operands rounded to bf16 inside the kernel,
-    fp32 accumulation -> equals the fp64 product of the bf16-ROUNDED operands to fp32 accumulation accuracy, the bias sums
-    stay exact-fp32, and shapes its vector loads cannot take fall back to the exact kernel."""
+def test_weight_grad_mma_modes(dev, monkeypatch, n_out, k_in, mode):
+    """rsn_weight_grad_multi_mode.  bf16 (the opt-in reduced-precision training mode): operands rounded to bf16 inside the
+    kernel, fp32 accumulation -> equals the fp64 product of the bf16-ROUNDED operands to fp32 accumulation accuracy.
+    bf16x6: operands split into bf16 triples, 6 products -> meets the exact kernel's bound against the fp64 product.
+    The bias sums stay exact fp32, and shapes the vector loads cannot take fall back to the exact kernel."""
     from reflect_sampling_nerf_amd import train_graph
 
     g = torch.Generator().manual_seed(n_out + k_in)
@@ -923,9 +925,13 @@ def test_weight_grad_bf16_variant(dev, monkeypatch, n_out, k_in):
         ref_b += dy.double().sum(0)
         segs.append((dy.to(dev), x.to(dev)))
     dw, db = torch.zeros(n_out, k_in, device=dev), torch.zeros(n_out, device=dev)
-    monkeypatch.setattr(train_graph, "_WGRAD_BF16", True)
+    monkeypatch.setattr(train_graph, "_WGRAD_MODE", {"bf16": 3, "bf16x6": 1}[mode])
     train_graph._wgrad_multi(segs, n_out, k_in, dw, 0, db)
     got = dw.double().cpu()
+    if mode == "bf16x6":
+        assert float((got - exact_w).abs().max()) <= 2e-5 * float(exact_w.abs().max())
+        assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+        return
     vector_path = n_out > 32 and k_in % (8 if k_in > 128 else 4 if k_in > 64 else 2) == 0
     target = ref_w if vector_path else exact_w
     assert float((got - target).abs().max()) <= 2e-5 * float(target.abs().max())

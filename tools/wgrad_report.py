@@ -20,9 +20,13 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--define", action="append", default=[], help="extra -D macros: times an experimental build")
     ap.add_argument("--quick", action="store_true", help="only the two large point counts")
+    ap.add_argument("--mode", default="f32", choices=["f32", "bf16x6", "bf16"], help="MMA mode of the reduction")
     args = ap.parse_args()
     import reflect_sampling_nerf_amd as pkg
+    from reflect_sampling_nerf_amd import train_graph
     from reflect_sampling_nerf_amd.train_graph import _wgrad
+
+    train_graph._WGRAD_MODE = {"f32": 0, "bf16x6": 1, "bf16": 3}[args.mode]
 
     if args.define:
         from tools._variant import build_variant
