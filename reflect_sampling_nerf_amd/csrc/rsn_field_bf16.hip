@@ -810,10 +810,20 @@ __device__ __forceinline__ void gemm_ring16(f32x4 (&acc)[NBO][2], const bf16x8 (
     const int kk = i / NBO, b = i % NBO;
     const bf16x8 wa = W[i % RING_FIFO];
     const int pos = (i % RSN_RING_GROUP_FRAGS) + RING_FIFO;
+#ifndef RSN_R16_NO_LDS_READ  // timing diagnostics (tools/variant_bench.py --define): wrong results by construction
     W[i % RING_FIFO] = *reinterpret_cast<const bf16x8*>(
         smem + (pos < RSN_RING_GROUP_FRAGS ? r.rd_cur + pos * 1024 : r.rd_next + (pos - RSN_RING_GROUP_FRAGS) * 1024));
+#endif
+#ifndef RSN_R16_NO_MFMA
     acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][0], acc[b][0], 0, 0, 0);
     acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][1], acc[b][1], 0, 0, 0);
+#else
+    acc[b][0][i % 4] += (float)wa[0] * (float)X[kk][0][0];
+#endif
+#ifdef RSN_R16_DOUBLE_MFMA  // the MFMA work of a 64-point tile per fragment read (results wrong)
+    acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][1], acc[b][0], 0, 0, 0);
+    acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][0], acc[b][1], 0, 0, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }
