@@ -238,7 +238,9 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
                        nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
     params = model.get_param_groups()["fields"]
     optimizer = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15, lr_final=1e-4, max_steps=50000)  # config.py:50-53
-    reducer = FlatGradAllReduce(params) if world > 1 else None
+    reducer = FlatGradAllReduce(params) if dist is not None else None
+    if reducer is not None and world == 1:
+        reducer.run_single_rank = True  # RSN_BENCH_FORCE_COLLECTIVE rehearsal
     batch = {"image": torch.rand(R, 3, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)}
     state = {"it": 100, "M": 0, "loss": None}  # past the 50-step loss warm-up: all eight loss terms are live
 
@@ -421,7 +423,12 @@ def main():
     dev = torch.device("cuda", dev_index)
     dist = None
     backend = None
-    if world > 1:
+    # RSN_BENCH_FORCE_COLLECTIVE=1: the N > 1 code path (process group on RCCL, gradient all-reduce on the side stream,
+    # barriers, MAX over ranks) with ONE rank -- the rehearsal a 1-GPU box allows on the real backend
+    force = os.environ.get("RSN_BENCH_FORCE_COLLECTIVE") == "1" and world == 1
+    if force:
+        os.environ.setdefault("MASTER_PORT", "29542")
+    if world > 1 or force:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -455,10 +462,10 @@ def main():
                                     "+ 8-term loss + backward + %s + fused RAdam; M/R = %.2f"
                                     % (R, samples[0], samples[1], samples[2], samples[3], args.layers, args.width,
                                        ("ONE flat 618513-float gradient all-reduce (%s, %d ranks)" % (backend, world))
-                                       if world > 1 else "no collective (N=1)", rec["reflect_ray_fraction"]),
+                                       if dist is not None else "no collective (N=1)", rec["reflect_ray_fraction"]),
                         "rays_per_gpu": R, "samples_per_ray": S, "global_rays_per_step": world * R,
                         "parallelism": "dp%d" % world,
-                        "collective": None if world == 1 else "all-reduce(sum)/N of one flat fp32 gradient buffer per step",
+                        "collective": None if dist is None else "all-reduce(sum)/N of one flat fp32 gradient buffer per step",
                         "rccl_ranks": dist.get_world_size() if (dist is not None and backend == "nccl") else 0,
                         "backend": backend,
                         "weights": "random-init (nn.Linear default), seed 0, density bias +2",

@@ -38,6 +38,7 @@ class FlatGradAllReduce:
         self._flags: Dict[Tuple[bool, ...], torch.Tensor] = {}
         self._stream = None
         self.host_syncs = 0  # device->host reads issued by the reducer (tests assert it stays at the one-time 1)
+        self.run_single_rank = False  # tests: issue the collective in a one-rank group too (RCCL + side stream on one GPU)
 
     # ------------------------------------------------------------------------------------------------ one-time set-up
     def _decide_live(self) -> None:
@@ -73,7 +74,7 @@ class FlatGradAllReduce:
         if not dist.is_available() or not dist.is_initialized():
             return
         world = dist.get_world_size(self.group)
-        if world == 1:
+        if world == 1 and not self.run_single_rank:
             return
         if self.params is None:
             self._decide_live()

@@ -2,6 +2,8 @@
 inputs.  Tolerance (BASELINE.json north_star): 1e-4 absolute, fp32, on rendered RGB and accumulation; the
 same bound is applied to every continuous output.  Discontinuous outputs (mask, median-depth bin) are compared
 exactly except at samples that sit within 1e-5 of their threshold."""
+import os
+
 import pytest
 import torch
 
@@ -1285,3 +1287,39 @@ def test_baseline_config3_bf16_properties(dev):
     assert max_abs(lv["color"][:512], ref["color"]) <= 3e-2
     rel = (lv["sigma"][:512] - ref["sigma"]).abs() / (1.0 + ref["sigma"].abs())
     assert float(rel.max()) <= 3e-2
+
+
+def test_reducer_on_rccl_single_rank(dev):
+    """The reducer's production path -- backend "nccl" (RCCL), all-reduce on the side stream, events, device-resident
+    flags -- on the one GPU a test box has: a one-rank group (world_size 1; two ranks cannot share a device under RCCL).
+    The average over one rank is the identity: every gradient survives bit for bit, a parameter without gradient stays
+    None, and steady state issues no device->host read.  The N > 1 arithmetic is covered on gloo (test_parallel_cpu.py,
+    tools/ddp_equiv.py)."""
+    import torch.distributed as dist
+    from reflect_sampling_nerf_amd.parallel import FlatGradAllReduce
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.Generator().manual_seed(5)
+        params = [torch.nn.Parameter(torch.randn(n, generator=g).to(dev)) for n in (7, 256 * 256, 3, 1000)]
+        red = FlatGradAllReduce(params)
+        red.run_single_rank = True
+        for step in range(3):
+            grads = [torch.randn(p.shape, generator=g).to(dev) for p in params]
+            for p, gr in zip(params, grads):
+                p.grad = gr.clone()
+            params[2].grad = None if step == 0 else params[2].grad  # unused on "every rank" in the first step: dropped
+            red()
+            torch.cuda.synchronize()
+            for i, (p, gr) in enumerate(zip(params, grads)):
+                if i == 2:
+                    continue
+                assert torch.equal(p.grad, gr)
+        assert all(q is not params[2] for q in red.params)  # decided once, on the first call
+        assert red.host_syncs == 1
+    finally:
+        dist.destroy_process_group()
