@@ -274,6 +274,13 @@ class GetOutputsTrain(torch.autograd.Function):
         lf = fld.evaluate_frustums_train(o, d, pa, eb_f, want_normals=True)
         cf = ops.composite(R, None, Sf, 1, CLIP, lf["sigma"], eb_f, lf["color"], level=lf, surface=True)
         rs = ops.reflect_setup(o, d, cf["accumulation"], cf["depth"], cf["normals"], cf["roughness"], float(model.far))
+        # everything the reflect branch needs that does not depend on M is prepared BEFORE the host read below: the GPU
+        # drains its queue while the host waits, so every microsecond between the read and the next field launch is idle
+        lib = _abi.load_library()
+        W, L = fld.width, fld.mlp_base.num_layers
+        desc = fld.field_desc()
+        pk = fld.packed_weights()
+        mask_bool = rs["mask"].bool()
         M = int(rs["n_masked"].item())  # training: one sync here sizes the reflect buffers exactly
         model._last_num_reflected = M
 
@@ -282,7 +289,7 @@ class GetOutputsTrain(torch.autograd.Function):
             "depth_coarse": cc["depth"].unsqueeze(-1), "depth_fine": cf["depth"].unsqueeze(-1),
             "weights_coarse": cc["weights"].unsqueeze(-1), "weights_fine": cf["weights"].unsqueeze(-1),
             "normals_coarse": lc["normals"], "normals_fine": lf["normals"],
-            "diff": cf["diff"], "tint": cf["tint"], "mask": rs["mask"].bool(),
+            "diff": cf["diff"], "tint": cf["tint"], "mask": mask_bool,
         }
         st = dict(R=R, M=M, eb_c=eb_c, eb_f=eb_f, lc=lc, lf=lf, cc=cc, cf=cf, rs=rs, rays=(o, d, pa))
         if M > 0:
@@ -290,16 +297,12 @@ class GetOutputsTrain(torch.autograd.Function):
             pa2, sq = rs["pixel_area2"][:M].contiguous(), rs["sqradius"][:M].contiguous()
             near2, far2 = rs["nears2"][:M].contiguous(), rs["fars2"][:M].contiguous()
             nm = rs["n_masked"]
-            lib = _abi.load_library()
             # get_inf_color in training mode (activations saved)
-            W, L = fld.width, fld.mlp_base.num_layers
             f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
             inf_saved = {"enc": f(M, 104), "act": f(L, M, W), "bott": f(M, W), "sh": f(M, 40), "hid": f(M, 128),
                          "heads": f(M, 8), "relu_bits": torch.empty(L + 1, M, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
             bg = f(M, 3)
-            desc = fld.field_desc()
             fs = _saved_struct(inf_saved)
-            pk = fld.packed_weights()
             ops.timed("field_forward_train", {"points": M}, lambda: check(
                 lib.rsn_field_forward_inf_train(C.byref(desc), ptr(pk), M, None, ptr(d2), ptr(sq), ptr(bg), C.byref(fs),
                                                 ops._stream())))
