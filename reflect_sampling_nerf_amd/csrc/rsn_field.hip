@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
   const long long n_tiles = (n_points + 127) / 128;
   const float* __restrict__ pk = a.packed;
 #ifdef RSN_PHASE_TIMERS
-  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tacc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = clock64();
 #endif
 
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       }
       f32x16 eacc[4];
       zero_acc<4>(eacc);
+      RSN_T(13);
 #pragma unroll 1
       for (int l = a.num_layers - 1; l >= 1; --l) {
         if (l == a.skip_layer) gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, ln);
@@ -375,10 +376,14 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[NB];
         zero_acc<NB>(acc);
+        RSN_T(13);
         gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
+        RSN_T(12);
         store_masked_bits<NB>(acc, X, mb, h);
       }
+      RSN_T(13);
       gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, ln);
+      RSN_T(12);
       store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
       float nrm[3];
 #pragma unroll 1
@@ -408,12 +413,13 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         a.saved.normals[pc * 3 + 1] = -(nrm[1] / len);
         a.saved.normals[pc * 3 + 2] = -(nrm[2] / len);
       }
+      RSN_T(14);
     }
   }
 #ifdef RSN_PHASE_TIMERS
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) atomicAdd(&rsn_phase_cycles[i], (unsigned long long)tacc[i]);
+    for (int i = 0; i < 15; ++i) atomicAdd(&rsn_phase_cycles[i], (unsigned long long)tacc[i]);
     atomicAdd(&rsn_phase_cycles[15], 1ull);
   }
 #endif
