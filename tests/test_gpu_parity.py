@@ -1169,7 +1169,8 @@ def test_baseline_config2_training_step_properties(dev):
     torch.manual_seed(123)
     out2 = model(rb)
     loss2 = sum(model.get_loss_dict(out2, batch).values())
-    assert abs(float(loss2.detach()) - l1) <= 1e-6 * abs(l1)
+    # (the loss terms are sums of ~2,000 block partials added by fp32 atomics: their order moves the total by ~1e-6)
+    assert abs(float(loss2.detach()) - l1) <= 1e-5 * abs(l1)
     # a few optimiser steps move every trained tensor and keep everything finite
     before = [p.detach().clone() for p in params]
     losses = [float(train_step(model, rb, batch, opt, None, 100 + k)) for k in range(3)]
