@@ -213,7 +213,8 @@ class ReflectSamplingNeRFNerfField(Field):
         return level
 
     def evaluate_frustums_train(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid_bins: Tensor,
-                                n_dev: Optional[Tensor] = None, want_normals: bool = True) -> Dict[str, Tensor]:
+                                n_dev: Optional[Tensor] = None, want_normals: bool = True,
+                                work: Optional[Dict] = None) -> Dict[str, Tensor]:
         """Training-mode level: same per-sample outputs as evaluate_frustums plus `raw_density`, the analytic
         `normals` (Field.get_normals, when want_normals) and `saved` = the activations the backward pass needs."""
         lib = _abi.load_library()
@@ -233,7 +234,9 @@ class ReflectSamplingNeRFNerfField(Field):
             setattr(fs, k, ptr(v))
         desc = self.field_desc()
         pk = self.packed_weights()
-        ops.timed("field_forward_train_normals" if want_normals else "field_forward_train", {"points": N}, lambda: check(
+        if work is None:  # (a caller launching with a device-side ray count fills in the evaluated points later)
+            work = {"points": N}
+        ops.timed("field_forward_train_normals" if want_normals else "field_forward_train", work, lambda: check(
             lib.rsn_field_forward_frustum_train(C.byref(desc), ptr(pk), R, ptr(n_dev), S, ptr(origins), ptr(directions),
                                                 ptr(pixel_area), ptr(euclid_bins), C.byref(fo), C.byref(fs),
                                                 ops._stream())))

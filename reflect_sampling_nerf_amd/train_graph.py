@@ -66,7 +66,7 @@ def _unpermute(g_slots: Tensor, cols: List[int], width: int) -> Tensor:
 
 # ------------------------------------------------------------------------------------------------ thin wrappers
 def _composite_backward(n, S, background, flags, detach_w, level, eb, weights, g_rgb, bg=None, g_rough=None,
-                        want_sigma=True, want_bg=False, rough_samples=None, g_acc=None):
+                        want_sigma=True, want_bg=False, rough_samples=None, g_acc=None, n_dev=None):
     lib = _abi.load_library()
     dev = g_rgb.device
     out = {"g_color": torch.empty(n, S, 3, device=dev)}
@@ -82,7 +82,7 @@ def _composite_backward(n, S, background, flags, detach_w, level, eb, weights, g
     io.g_accumulation = ptr(g_acc)
     io.g_sigma, io.g_color = ptr(out.get("g_sigma")), ptr(out["g_color"])
     io.g_roughness_sample, io.g_bg = ptr(out.get("g_rough")), ptr(out.get("g_bg"))
-    check(lib.rsn_composite_backward(n, None, S, background, flags, detach_w, io, ops._stream()))
+    check(lib.rsn_composite_backward(n, ptr(n_dev), S, background, flags, detach_w, io, ops._stream()))
     return out
 
 
@@ -167,8 +167,18 @@ def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Opti
 
 def _weight_grads(field, levels, acc: _GradAcc):
     """dW = dY^T X (+ db) for every linear layer, reduced over all field evaluations of the step at once.
-    levels: list of (saved activations, backward-sweep outputs, with_heads)."""
+    levels: list of (saved activations, backward-sweep outputs, with_heads[, valid rows]).  Buffers of an evaluation that
+    was launched with a device-side ray count are sized for the upper bound: only their first `valid rows` rows exist."""
     global _WGRAD_MODE
+    cut = []
+    for lv in levels:
+        sv, go, wh = lv[0], lv[1], lv[2]
+        nv = lv[3] if len(lv) > 3 else None
+        if nv is not None:
+            sv = {k: (v[:, :nv] if k in ("act", "relu_bits") else v[:nv]) for k, v in sv.items()}
+            go = {k: (v[:, :nv] if k == "dy" else v[:nv]) for k, v in go.items()}
+        cut.append((sv, go, wh))
+    levels = cut
     _WGRAD_MODE = int(field.mma_mode)  # bf16x6: split operands (fp32-equivalent); bf16: rounded operands (reduced precision)
     L, W = field.mlp_base.num_layers, field.width
     skip = field.field_desc().skip_layer
@@ -194,7 +204,8 @@ def _weight_grads(field, levels, acc: _GradAcc):
     _wgrad_multi([(go["dz_heads"], sv["act"][L - 1]) for sv, go, wh in levels if wh], 16, W, acc.heads_w, 0, acc.heads_b)
 
 
-def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], need_input: bool):
+def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], need_input: bool, n_dev=None,
+                    work: Optional[Dict] = None):
     lib = _abi.load_library()
     o, d, pa = rays
     n, S = eb.shape[0], eb.shape[1] - 1
@@ -206,17 +217,17 @@ def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], ne
     fs = _saved_struct(level["saved"])
     desc = field.field_desc()
     pk = field.packed_weights()
-    ops.timed("field_backward_input" if need_input else "field_backward", {"points": n * S}, lambda: check(
-        lib.rsn_field_backward_frustum(C.byref(desc), ptr(pk), n, None, S, ptr(o), ptr(d), ptr(pa), ptr(eb),
+    ops.timed("field_backward_input" if need_input else "field_backward", work or {"points": n * S}, lambda: check(
+        lib.rsn_field_backward_frustum(C.byref(desc), ptr(pk), n, ptr(n_dev), S, ptr(o), ptr(d), ptr(pa), ptr(eb),
                                        C.byref(fo), C.byref(fs), C.byref(gi), C.byref(gst), 1 if need_input else 0,
                                        ops._stream())))
     return gout
 
 
-def _ray_sum(x: Tensor, n: int, S: int) -> Tensor:
+def _ray_sum(x: Tensor, n: int, S: int, n_dev=None) -> Tensor:
     lib = _abi.load_library()
     out = torch.empty(n, device=x.device)
-    check(lib.rsn_ray_sum(n, None, S, ptr(x), ptr(out), ops._stream()))
+    check(lib.rsn_ray_sum(n, ptr(n_dev), S, ptr(x), ptr(out), ops._stream()))
     return out
 
 
@@ -243,23 +254,37 @@ class GetOutputsTrain(torch.autograd.Function):
         jitter = jitter or {}
         bins = bins or {}
 
-        def jit(name, n, S, rows=None):
+        def pad_rows(t, n):
+            """[m, ...] -> [n, ...] (m <= n), zero rows behind: device-counted launches ignore them"""
+            if t.shape[0] == n:
+                return t
+            out = torch.zeros((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+            out[: t.shape[0]] = t
+            return out
+
+        def jit(name, n, S, rows=None, n_valid=None):
             """the level's uniform draws [n, S+1]: injected ones (validated: the kernel reads n*(S+1) floats) or fresh.
-            Reflect levels also accept draws per ORIGINAL ray [R, S+1]: the rows of this pass's reflected rays are used."""
+            Reflect levels (launched for n = R rows with a device-side count, n_valid of them real) also accept draws per
+            ORIGINAL ray [R, S+1] -- the rows of this pass's reflected rays are used -- or per reflected ray [n_valid, S+1]."""
             t = jitter.get(name)
             if t is None:
                 return torch.rand(n, S + 1, device=dev)
             t = ops._f32c(t.to(dev))
-            if rows is not None and t.shape[0] == R and n != R:
-                t = t[rows[:n].long()].contiguous()
+            if rows is not None and t.shape[0] == R and n_valid != R:
+                t = t[rows[:n_valid].long()].contiguous()
+            if n_valid is not None:
+                if tuple(t.shape) != (n_valid, S + 1):
+                    raise ValueError(f"jitter[{name!r}] has shape {tuple(t.shape)}, expected {(n_valid, S + 1)}")
+                return pad_rows(t, n)
             if tuple(t.shape) != (n, S + 1):
                 raise ValueError(f"jitter[{name!r}] has shape {tuple(t.shape)}, expected {(n, S + 1)}")
             return t
 
-        def level_bins(name, n, S, sample):
+        def level_bins(name, n, S, sample, n_valid=None):
             """the level's (spacing, euclidean) bins: injected ones if given, else the sampler launch `sample()`"""
             if name + "_euclid" in bins:
-                sb, eb = (ops._f32c(bins[name + k].to(dev).reshape(n, S + 1)) for k in ("_spacing", "_euclid"))
+                m = n if n_valid is None else n_valid
+                sb, eb = (pad_rows(ops._f32c(bins[name + k].to(dev).reshape(m, S + 1)), n) for k in ("_spacing", "_euclid"))
                 return sb, eb
             return sample()
 
@@ -274,14 +299,53 @@ class GetOutputsTrain(torch.autograd.Function):
         lf = fld.evaluate_frustums_train(o, d, pa, eb_f, want_normals=True)
         cf = ops.composite(R, None, Sf, 1, CLIP, lf["sigma"], eb_f, lf["color"], level=lf, surface=True)
         rs = ops.reflect_setup(o, d, cf["accumulation"], cf["depth"], cf["normals"], cf["roughness"], float(model.far))
-        # everything the reflect branch needs that does not depend on M is prepared BEFORE the host read below: the GPU
-        # drains its queue while the host waits, so every microsecond between the read and the next field launch is idle
+        # C.-F. the reflect branch runs on the M <= R rays behind the mask.  Like the eval path (model.get_outputs) every
+        # launch is sized for R rays and takes the count from device memory (rs["n_masked"]): the host reads M only AFTER the
+        # whole branch is enqueued (it needs it for the [M, 1] output and for the weight-gradient segment lengths), so the
+        # read overlaps the reflect levels instead of idling the GPU between the fine level and the first reflect launch.
+        nm = rs["n_masked"]
         lib = _abi.load_library()
         W, L = fld.width, fld.mlp_base.num_layers
+        # injected draws / bins come in the reference's shapes ([M, S + 1]): that mode reads M first
+        M = int(nm.item()) if (jitter or bins) else None
+        if M is None:
+            # the copy of the count is ISSUED here, right behind reflect_setup, into pinned host memory, and awaited (event)
+            # after the reflect levels are enqueued: the wait ends when the GPU has passed this point, not the levels
+            if getattr(model, "_nm_host", None) is None:
+                model._nm_host = torch.empty(1, dtype=torch.int32).pin_memory()
+                model._nm_event = torch.cuda.Event()
+            model._nm_host.copy_(nm, non_blocking=True)
+            model._nm_event.record()
+        o2, d2, pa2, sq = rs["origins2"], rs["directions2"], rs["pixel_area2"], rs["sqradius"]
+        near2, far2 = rs["nears2"], rs["fars2"]
+        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        # get_inf_color in training mode (activations saved)
+        inf_saved = {"enc": f(R, 104), "act": f(L, R, W), "bott": f(R, W), "sh": f(R, 40), "hid": f(R, 128),
+                     "heads": f(R, 8), "relu_bits": torch.empty(L + 1, R, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
+        bg = f(R, 3)
         desc = fld.field_desc()
+        fs = _saved_struct(inf_saved)
         pk = fld.packed_weights()
+        work_inf, work_rc, work_rf = {"points": 0}, {"points": 0}, {"points": 0}
+        ops.timed("field_forward_train", work_inf, lambda: check(
+            lib.rsn_field_forward_inf_train(C.byref(desc), ptr(pk), R, ptr(nm), ptr(d2), ptr(sq), ptr(bg), C.byref(fs),
+                                            ops._stream())))
+        sb_rc, eb_rc = level_bins("reflect_coarse", R, Src, lambda: ops.sample_spaced(
+            R, nm, Src, rec.spacing, rec.tan, near2, far2, jit("reflect_coarse", R, Src, rs["ray_index"], M)), M)
+        lrc = fld.evaluate_frustums_train(o2, d2, pa2, eb_rc, n_dev=nm, want_normals=False, work=work_rc)
+        crc = ops.composite(R, nm, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
+        ops.reflect_combine(R, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
+        sb_rf, eb_rf = level_bins("reflect_fine", R, Srf, lambda: ops.sample_pdf(
+            R, nm, Src, Srf, rec.spacing, rec.tan, model.sampler_reflect_pdf.histogram_padding, near2, far2,
+            crc["weights"], sb_rc, jit("reflect_fine", R, Srf, rs["ray_index"], M)), M)
+        lrf = fld.evaluate_frustums_train(o2, d2, pa2, eb_rf, n_dev=nm, want_normals=False, work=work_rf)
+        crf = ops.composite(R, nm, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
+        ops.reflect_combine(R, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
         mask_bool = rs["mask"].bool()
-        M = int(rs["n_masked"].item())  # training: one sync here sizes the reflect buffers exactly
+        if M is None:
+            model._nm_event.synchronize()  # the step's one host wait; the reflect levels are already queued behind it
+            M = int(model._nm_host[0])
+        work_inf["points"], work_rc["points"], work_rf["points"] = M, M * Src, M * Srf
         model._last_num_reflected = M
 
         aux = {
@@ -293,38 +357,18 @@ class GetOutputsTrain(torch.autograd.Function):
         }
         st = dict(R=R, M=M, eb_c=eb_c, eb_f=eb_f, lc=lc, lf=lf, cc=cc, cf=cf, rs=rs, rays=(o, d, pa))
         if M > 0:
-            o2, d2 = rs["origins2"][:M].contiguous(), rs["directions2"][:M].contiguous()
-            pa2, sq = rs["pixel_area2"][:M].contiguous(), rs["sqradius"][:M].contiguous()
-            near2, far2 = rs["nears2"][:M].contiguous(), rs["fars2"][:M].contiguous()
-            nm = rs["n_masked"]
-            # get_inf_color in training mode (activations saved)
-            f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
-            inf_saved = {"enc": f(M, 104), "act": f(L, M, W), "bott": f(M, W), "sh": f(M, 40), "hid": f(M, 128),
-                         "heads": f(M, 8), "relu_bits": torch.empty(L + 1, M, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
-            bg = f(M, 3)
-            fs = _saved_struct(inf_saved)
-            ops.timed("field_forward_train", {"points": M}, lambda: check(
-                lib.rsn_field_forward_inf_train(C.byref(desc), ptr(pk), M, None, ptr(d2), ptr(sq), ptr(bg), C.byref(fs),
-                                                ops._stream())))
-            sb_rc, eb_rc = level_bins("reflect_coarse", M, Src, lambda: ops.sample_spaced(
-                M, None, Src, rec.spacing, rec.tan, near2, far2, jit("reflect_coarse", M, Src, rs["ray_index"])))
-            lrc = fld.evaluate_frustums_train(o2, d2, pa2, eb_rc, want_normals=False)
-            crc = ops.composite(M, None, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
-            ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
-            sb_rf, eb_rf = level_bins("reflect_fine", M, Srf, lambda: ops.sample_pdf(
-                M, None, Src, Srf, rec.spacing, rec.tan, model.sampler_reflect_pdf.histogram_padding, near2, far2,
-                crc["weights"], sb_rc, jit("reflect_fine", M, Srf, rs["ray_index"])))
-            lrf = fld.evaluate_frustums_train(o2, d2, pa2, eb_rf, want_normals=False)
-            crf = ops.composite(M, None, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
-            ops.reflect_combine(M, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
-            aux["depth_reflect_fine"] = crf["depth"].unsqueeze(-1)
+            aux["depth_reflect_fine"] = crf["depth"][:M].unsqueeze(-1)
             st.update(rays2=(o2, d2, pa2), sq=sq, bg=bg, inf_saved=inf_saved, eb_rc=eb_rc, eb_rf=eb_rf, lrc=lrc, lrf=lrf,
                       crc=crc, crf=crf)
         if getattr(model, "_keep_train_state", False):  # test hook: the sample positions this pass evaluated
-            st.update(sb_c=sb_c, sb_f=sb_f)
-            if M > 0:
-                st.update(sb_rc=sb_rc, sb_rf=sb_rf)
-            model._train_state = st
+            exp = dict(st, sb_c=sb_c, sb_f=sb_f)
+            if M > 0:  # the reflect levels' buffers are sized for R rays: the hook shows their M real rows
+                def trim(lv, n):
+                    sv = {k: (v[:, :n] if k in ("act", "relu_bits") else v[:n]) for k, v in lv["saved"].items()}
+                    return dict(lv, saved=sv)
+                exp.update(sb_rc=sb_rc[:M], sb_rf=sb_rf[:M], eb_rc=eb_rc[:M], eb_rf=eb_rf[:M],
+                           lrc=trim(lrc, M * Src), lrf=trim(lrf, M * Srf))
+            model._train_state = exp
         ctx.st = st
         ctx.model = model
         ctx.n_params = len(params)
@@ -353,29 +397,32 @@ class GetOutputsTrain(torch.autograd.Function):
         g_rough_ray = z(g_rough, R, 1).reshape(R).clone()
 
         if M > 0:
+            # everything of the reflect branch is sized for R rays and launched with the device-side count (see forward);
+            # the weight gradients take the first M (x samples) rows
             nm = rs["n_masked"]
-            g_bg = torch.zeros(M, 3, device=dev)
-            g_pa2 = torch.zeros(M, device=dev)
+            g_bg = torch.zeros(R, 3, device=dev)
+            g_pa2 = torch.zeros(R, device=dev)
             for eb, lv, cp, g_out, S in ((st["eb_rf"], st["lrf"], st["crf"], g_refl_f, Srf),
                                          (st["eb_rc"], st["lrc"], st["crc"], g_refl_c, Src)):
-                g_comp = torch.empty(M, 3, device=dev)
-                check(lib.rsn_reflect_combine_backward(M, ptr(nm), ptr(rs["ray_index"]), ptr(cf["diff"]), ptr(cf["tint"]),
+                g_comp = torch.empty(R, 3, device=dev)
+                check(lib.rsn_reflect_combine_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(cf["diff"]), ptr(cf["tint"]),
                                                        ptr(cp["rgb"]), ptr(g_out), ptr(g_comp), ops._stream()))
-                cb = _composite_backward(M, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
-                                         want_bg=True)
-                g_bg += cb["g_bg"]
-                gout = _field_backward(fld, st["rays2"], eb, lv, {"color": cb["g_color"]}, need_input=True)
-                g_pa2 += _ray_sum(gout["d_input"], M, S)
-                pending.append((lv["saved"], gout, True))
+                cb = _composite_backward(R, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
+                                         want_bg=True, n_dev=nm)
+                g_bg[:M] += cb["g_bg"][:M]
+                gout = _field_backward(fld, st["rays2"], eb, lv, {"color": cb["g_color"]}, need_input=True, n_dev=nm,
+                                       work={"points": M * S})
+                g_pa2[:M] += _ray_sum(gout["d_input"], R, S, nm)[:M]
+                pending.append((lv["saved"], gout, True, M * S))
             # get_inf_color
-            gout, gst = _alloc_gout(fld, M, dev, True)
+            gout, gst = _alloc_gout(fld, R, dev, True)
             desc = fld.field_desc()
             fs = _saved_struct(st["inf_saved"])
             pk = fld.packed_weights()
             ops.timed("field_backward_input", {"points": M}, lambda: check(
-                lib.rsn_field_backward_inf(C.byref(desc), ptr(pk), M, None, ptr(st["rays2"][1]), ptr(st["sq"]),
+                lib.rsn_field_backward_inf(C.byref(desc), ptr(pk), R, ptr(nm), ptr(st["rays2"][1]), ptr(st["sq"]),
                                            C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream())))
-            pending.append((st["inf_saved"], gout, False))
+            pending.append((st["inf_saved"], gout, False, M))
             g_r = torch.empty(R, device=dev)
             check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
                                            ptr(gout["d_input"]), ptr(g_pa2), ptr(g_r), ops._stream()))
