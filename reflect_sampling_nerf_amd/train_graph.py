@@ -2,7 +2,8 @@
 `self.training`, with torch autograd building the graph op by op).
 
 forward  = samplers (stratified jitter) -> fused field kernels in training mode (activations saved, analytic
-           normals by a dX sweep) -> compositing -> reflected rays (one host sync: M sizes the reflect buffers).
+           normals by a dX sweep) -> compositing -> reflected rays (sized for R rays, the count M read from device memory
+           by every launch; the host awaits M once, behind the enqueued reflect levels).
 backward = the same pipeline reversed through librsn_hip.so: reflect combine / composite backward (suffix scan),
            rsn_field_backward_* (transposed-weight MFMA sweep producing every layer's pre-activation gradient),
            then rsn_weight_grad: dW = dY^T X and db for every linear layer (output-stationary MFMA reduction over
