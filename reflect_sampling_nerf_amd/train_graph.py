@@ -232,6 +232,20 @@ def _ray_sum(x: Tensor, n: int, S: int, n_dev=None) -> Tensor:
     return out
 
 
+_MAILBOX: Dict[int, tuple] = {}
+
+
+def _count_mailbox(dev):
+    """(pinned int32[1], event) per device: where the reflected-ray count lands on the host.  Module state, not model
+    state: a model stays free of pinned memory and of HIP events (deepcopy, pickling by the host framework)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    box = _MAILBOX.get(key)
+    if box is None:
+        box = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        _MAILBOX[key] = box
+    return box
+
+
 # ------------------------------------------------------------------------------------------------ the autograd node
 DIFF_KEYS = ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "pred_normals_coarse",
              "pred_normals_fine", "n_dot_d_coarse", "n_dot_d_fine", "roughness")
@@ -312,11 +326,9 @@ class GetOutputsTrain(torch.autograd.Function):
         if M is None:
             # the copy of the count is ISSUED here, right behind reflect_setup, into pinned host memory, and awaited (event)
             # after the reflect levels are enqueued: the wait ends when the GPU has passed this point, not the levels
-            if getattr(model, "_nm_host", None) is None:
-                model._nm_host = torch.empty(1, dtype=torch.int32).pin_memory()
-                model._nm_event = torch.cuda.Event()
-            model._nm_host.copy_(nm, non_blocking=True)
-            model._nm_event.record()
+            nm_host, nm_event = _count_mailbox(dev)
+            nm_host.copy_(nm, non_blocking=True)
+            nm_event.record()
         o2, d2, pa2, sq = rs["origins2"], rs["directions2"], rs["pixel_area2"], rs["sqradius"]
         near2, far2 = rs["nears2"], rs["fars2"]
         f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
@@ -344,8 +356,8 @@ class GetOutputsTrain(torch.autograd.Function):
         ops.reflect_combine(R, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
         mask_bool = rs["mask"].bool()
         if M is None:
-            model._nm_event.synchronize()  # the step's one host wait; the reflect levels are already queued behind it
-            M = int(model._nm_host[0])
+            nm_event.synchronize()  # the step's one host wait; the reflect levels are already queued behind it
+            M = int(nm_host[0])
         work_inf["points"], work_rc["points"], work_rf["points"] = M, M * Src, M * Srf
         model._last_num_reflected = M
 
