@@ -22,10 +22,19 @@ One JSON line is printed by rank 0 (contract in the task statement), including
   eval_level   -- (N = 1) BASELINE configs[1]: 4096 rays x 128 samples fused forward + composite of one level, with
                   its own roofline and CPU baseline (the round-1 headline, kept for continuity).
 A stalled or failed step exits NON-ZERO (watchdog: rc 3, exception: rc 4 after printing the error to stderr).
+
+Launching: `python bench.py --gpus N` is enough at every N.  With N > 1 and no WORLD_SIZE in the environment the
+process starts N fresh children of itself (one rank per GPU over RCCL) before it touches any GPU, relays rank 0's JSON
+line and exits with the worst child code (`self_launch`).  Under `python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N` (WORLD_SIZE set) it is one of the ranks.  RSN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with
+gloo as the backend: the 2-rank rehearsal a one-GPU box allows.
 """
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -66,9 +75,10 @@ def parse():
     ap.add_argument("--coarse", type=int, default=0, help="coarse samples if different from --samples (configs[2]: 64)")
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--width", type=int, default=256)
-    ap.add_argument("--workload", default="train", choices=["train", "level", "get_outputs"],
+    ap.add_argument("--workload", default="train", choices=["train", "level", "get_outputs", "selftest"],
                     help="train = the BASELINE metric (default): full optimisation step; level = BASELINE configs[1], "
-                         "fused forward + composite of one sampling level (eval); get_outputs = full eval get_outputs")
+                         "fused forward + composite of one sampling level (eval); get_outputs = full eval get_outputs; "
+                         "selftest = launch plumbing only (process group over gloo on the CPU, no GPU work)")
     ap.add_argument("--mma", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="matrix-core arithmetic of the field kernels: f32 = exact fp32 MFMA (default); bf16x6 = fp32 "
                          "emulation by 3-way bf16 splits (fp32-equivalent); bf16x3 / bf16 = reduced precision (eval)")
@@ -406,14 +416,110 @@ def run_get_outputs(pkg, args, dev, steps, warmup, dog):
             "value": R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps}
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, popen=subprocess.Popen, grace=20.0, poll=0.2):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the driver's command shape): this process
+    touches NO GPU; it starts N fresh children of this same script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in their environment: what torch.distributed.run would set; the reference's layout, one
+    process per GPU under DDP, pipeline.py:72-77), relays rank 0's stdout (the one JSON line) and returns the WORST
+    child exit code -- the watchdog's 3 and the exception path's 4 come through unchanged, a child ended by signal k
+    reads as 128 + k.  Once one child has failed the others get `grace` seconds, then they are terminated by PID."""
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        procs.append(popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                           stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    relay = None
+    if getattr(procs[0], "stdout", None) is not None:
+        def _relay():
+            for raw in procs[0].stdout:  # the JSON line goes to stdout, library chatter ("[Gloo] ...") to stderr
+                text = raw.decode(errors="replace") if isinstance(raw, bytes) else raw
+                dst = sys.stdout if text.lstrip().startswith("{") else sys.stderr
+                dst.write(text)
+                dst.flush()
+        relay = threading.Thread(target=_relay, daemon=True)
+        relay.start()
+    codes = [None] * n
+    failed_at = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                rc = p.poll()
+                if rc is not None:
+                    codes[i] = 128 - rc if rc < 0 else rc
+                    if codes[i] != 0 and failed_at is None:
+                        failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > grace:
+            for i, p in enumerate(procs):  # the survivors sit in a collective that will never complete
+                if codes[i] is None:
+                    p.terminate()
+            t_kill = time.time() + 5.0
+            while time.time() < t_kill and any(p.poll() is None for p in procs):
+                time.sleep(poll)
+            for i, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
+                if codes[i] is None:
+                    codes[i] = 5  # ended by the launcher after another rank failed
+            break
+        time.sleep(poll)
+    if relay is not None:
+        relay.join(timeout=10.0)
+    worst = max(codes)
+    if worst != 0:
+        sys.stderr.write(json.dumps({"error": "bench.py --gpus %d: child exit codes %s" % (n, codes)}) + "\n")
+    return worst
+
+
+def run_selftest(rank, world):
+    """--workload selftest: the launch plumbing without a GPU (CPU tests): process group over gloo, one all-reduce,
+    rank 0 prints one line.  RSN_BENCH_SELFTEST_FAIL_RANK=r makes rank r die (SIGKILL) before the collective."""
+    if os.environ.get("RSN_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        os.kill(os.getpid(), signal.SIGKILL)
+    dog = Watchdog(rank, limit=float(os.environ.get("RSN_BENCH_WATCHDOG_S", "240")))
+    total = float(rank + 1)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([total], dtype=torch.float64)
+        dist.all_reduce(t)
+        total = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    dog.done.set()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": total}), flush=True)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the driver's command shape: no launcher.  Start the ranks as fresh children BEFORE anything here touches the
+        # GPU (never re-exec a process that initialised HIP) and exit with the worst child code.
+        if args.workload != "selftest" and os.environ.get("RSN_BENCH_SHARE_GPU") != "1":
+            have = torch.cuda.device_count()  # does not initialise the GPU
+            if have < args.gpus:
+                sys.stderr.write(json.dumps({"error": "bench.py --gpus %d: %d GPU(s) visible (RSN_BENCH_SHARE_GPU=1 "
+                                                      "rehearses N ranks on one GPU over gloo)" % (args.gpus, have)}) + "\n")
+                sys.exit(2)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.workload == "selftest":
+        run_selftest(rank, world)
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     # rehearsal on a 1-GPU box: RSN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
     # ranks on one device); the real run is one rank per GPU over RCCL ("nccl" backend on ROCm).
@@ -437,7 +543,7 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    dog = Watchdog(rank)
+    dog = Watchdog(rank, limit=float(os.environ.get("RSN_BENCH_WATCHDOG_S", "240")))
 
     import reflect_sampling_nerf_amd as pkg
 

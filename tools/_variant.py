@@ -1,8 +1,8 @@
-"""Builds an experimental variant of librsn_hip.so (extra -D macros) into a temporary directory; tools only."""
+"""Builds an experimental variant of librsn_hip.so (extra -D macros) beside the product library; tools only.
+The variant lands in build/variants/ (git-ignored; it travels to the GPU box with the snapshot when built here)."""
+import hashlib
 import os
-import subprocess
 import sys
-import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -11,9 +11,8 @@ sys.path.insert(0, REPO)
 def build_variant(defines):
     from reflect_sampling_nerf_amd import _build
 
-    tmp = tempfile.mkdtemp(prefix="rsn_variant_")
-    lib = os.path.join(tmp, "librsn_variant.so")
-    cmd = ["hipcc", *_build.FLAGS, *["-D" + d for d in defines], "-I", os.path.join(REPO, "include"), "-I", _build.CSRC,
-           *[os.path.join(_build.CSRC, s) for s in _build.SOURCES], "-o", lib]
-    subprocess.run(cmd, check=True)
-    return lib
+    flags = ["-D" + d for d in defines]
+    tag = hashlib.sha256(" ".join(flags).encode()).hexdigest()[:10]
+    out = os.path.join(REPO, "build", "variants")
+    os.makedirs(out, exist_ok=True)
+    return _build.build_library(extra_flags=flags, lib_path=os.path.join(out, "librsn_variant_%s.so" % tag))

@@ -21,7 +21,7 @@ unset RSN_BENCH_SHARE_GPU
 run 900 pytest_gpu python -m pytest tests -m gpu -q -s
 run 300 bench_default python bench.py
 export RSN_BENCH_SHARE_GPU=1
-run 300 bench_n2_shared python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 5 --warmup 2
+run 300 bench_n2_shared python bench.py --gpus 2 --steps 5 --warmup 2   # self-launching: no torchrun on the command line
 unset RSN_BENCH_SHARE_GPU
 tail -3 $OUT/pytest_gpu.log
 tail -c 600 $OUT/bench_default.log
