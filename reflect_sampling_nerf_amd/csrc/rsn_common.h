@@ -15,6 +15,9 @@
 #define RSN_AUX_ITS 6      // LDS K-iterations reserved for the SH inputs (even, for the K=16 steps)
 
 void rsn_set_error(const char* fmt, ...);
+int rsn_device_cus();                   // CU count of the current device (cached per device)
+bool rsn_env_flag(const char* name);
+int rsn_env_int(const char* name, int dflt);    // tools: A/B switches from the environment
 
 #define RSN_REQUIRE(cond, code, ...)        \
   do {                                      \

@@ -438,16 +438,7 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
   if (a.n_rays <= 0) return RSN_OK;
   const long long n_points = (long long)a.n_rays * a.S;
   const long long n_tiles = (n_points + 127) / 128;
-  static int cached_cus = 0;  // CU count of the current device (256 on MI355X), queried once
-  if (cached_cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cached_cus = n;
-    else
-      cached_cus = 256;
-  }
-  const int cus = cached_cus;
+  const int cus = rsn_device_cus();
   // one 4-wave workgroup per CU (one wave per SIMD, LDS slab 148 KiB at W=256): persistent tiles
   const long long grid = n_tiles < (long long)cus ? n_tiles : (long long)cus;
   hipStream_t st = (hipStream_t)stream;

@@ -318,15 +318,7 @@ static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
   const long long n_points = (long long)a.n_rays * a.S;
   a.act_stride = n_points * (long long)d->width;
   const long long n_tiles = (n_points + 127) / 128;
-  static int cached_cus = 0;
-  if (cached_cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cached_cus = n;
-    else
-      cached_cus = 256;
-  }
+  const int cached_cus = rsn_device_cus();
   const long long grid = n_tiles < (long long)cached_cus ? n_tiles : (long long)cached_cus;
   hipStream_t st = (hipStream_t)stream;
   const bool x6 = d->mma_mode == RSN_MMA_BF16X6;  // fp32-emulating split-bf16 sweeps (opt-in); else exact fp32

@@ -104,10 +104,12 @@ __device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3
 // ------------------------------------------------------------------------------------------------
 // MFMA K loop: acc[nb] += W_seg[nb-block] * X, weights double-buffered in registers.
 // ------------------------------------------------------------------------------------------------
-template <int NBO>
+// NBT = output blocks of the packed segment ([it][NBT][lane][4]); a wave that takes only NBO < NBT of them passes its
+// segment pointer already advanced to its first block (tools/probes/gemm_occ_probe.hip).
+template <int NBO, int NBT = NBO>
 __device__ __forceinline__ void load_w(float4 (&w)[NBO], const float4* __restrict__ wp, int it) {
 #pragma unroll
-  for (int nb = 0; nb < NBO; ++nb) w[nb] = wp[(it * NBO + nb) * 64];
+  for (int nb = 0; nb < NBO; ++nb) w[nb] = wp[(it * NBT + nb) * 64];
 }
 
 template <int NBO>
@@ -144,12 +146,12 @@ __device__ __forceinline__ void interleave_loads() {
 
 // First weight fragment of a segment: issued by the caller ahead of the epilogue in front of the GEMM so that its L2
 // round trip hides under that epilogue.
-template <int NBO>
+template <int NBO, int NBT = NBO>
 __device__ __forceinline__ void pre_w(float4 (&wa)[NBO], const float* __restrict__ wseg, int lane) {
-  load_w<NBO>(wa, reinterpret_cast<const float4*>(wseg) + lane, 0);
+  load_w<NBO, NBT>(wa, reinterpret_cast<const float4*>(wseg) + lane, 0);
 }
 
-template <int NBO>
+template <int NBO, int NBT = NBO>
 __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ wseg,
                                           const float4* xl, int n_it, int lane) {
   const float4* __restrict__ wp = reinterpret_cast<const float4*>(wseg) + lane;
@@ -159,14 +161,14 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], 
   int it = 0;
 #pragma unroll 1
   for (; it + 1 < n_it; it += 2) {
-    load_w<NBO>(wb, wp, it + 1);
+    load_w<NBO, NBT>(wb, wp, it + 1);
     bb = xl[(it + 1) * 64];
     mma4<NBO>(acc, wa, ba);
     interleave_loads<NBO>();
     __builtin_amdgcn_sched_barrier(0);
     {  // unconditional prefetch with a clamped index: one control path => exact vmcnt counts
       const int in = (it + 2 < n_it) ? it + 2 : n_it - 1;
-      load_w<NBO>(wa, wp, in);
+      load_w<NBO, NBT>(wa, wp, in);
       ba = xl[in * 64];
     }
     mma4<NBO>(acc, wb, bb);
@@ -176,12 +178,12 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], 
   if (it < n_it) mma4<NBO>(acc, wa, ba);
 }
 
-template <int NBO>
+template <int NBO, int NBT = NBO>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl, int n_it,
                                      int lane) {
   float4 wa[NBO];
-  pre_w<NBO>(wa, wseg, lane);
-  gemm_run<NBO>(acc, wa, wseg, xl, n_it, lane);
+  pre_w<NBO, NBT>(wa, wseg, lane);
+  gemm_run<NBO, NBT>(acc, wa, wseg, xl, n_it, lane);
 }
 
 // acc[nb][4q+j] = bias[nb*32 + 8q + 4h + j]: the accumulators start from the bias (what torch's addmm does),
@@ -302,11 +304,12 @@ __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NBO], const float* __res
 }
 
 // dispatch on the MMA mode: MODE 0 = fp32 MFMA over n_it K-iterations of 8, else split-bf16 over ceil(n_it/2) K=16 steps
-template <int MODE, int NBO>
+template <int MODE, int NBO, int NBT = NBO>
 __device__ __forceinline__ void gemm_mode(f32x16 (&acc)[NBO], const float* __restrict__ w32, const float* __restrict__ w16,
                                           const float4* xl, int n_it, int lane) {
+  static_assert(MODE == 0 || NBT == NBO, "the split-bf16 loops own every output block of their segment");
   if (MODE == 0) {
-    gemm<NBO>(acc, w32, xl, n_it, lane);
+    gemm<NBO, NBT>(acc, w32, xl, n_it, lane);
   } else {
     gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
   }
@@ -314,16 +317,17 @@ __device__ __forceinline__ void gemm_mode(f32x16 (&acc)[NBO], const float* __res
 
 // the same with the first fp32 weight fragment fetched early by the caller (pre_mode ... gemm_mode_run); the
 // split-bf16 loops fetch their own first fragment (pre_mode is a no-op for them)
-template <int MODE, int NBO>
+template <int MODE, int NBO, int NBT = NBO>
 __device__ __forceinline__ void pre_mode(float4 (&wa)[NBO], const float* __restrict__ w32, int lane) {
-  if (MODE == 0) pre_w<NBO>(wa, w32, lane);
+  if (MODE == 0) pre_w<NBO, NBT>(wa, w32, lane);
 }
 
-template <int MODE, int NBO>
+template <int MODE, int NBO, int NBT = NBO>
 __device__ __forceinline__ void gemm_mode_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ w32,
                                               const float* __restrict__ w16, const float4* xl, int n_it, int lane) {
+  static_assert(MODE == 0 || NBT == NBO, "the split-bf16 loops own every output block of their segment");
   if (MODE == 0) {
-    gemm_run<NBO>(acc, wa, w32, xl, n_it, lane);
+    gemm_run<NBO, NBT>(acc, wa, w32, xl, n_it, lane);
   } else {
     gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
   }

@@ -6,6 +6,7 @@
 // accumulator registers a lane holds after one layer are exactly the B-operand values the same
 // lane needs for the next layer (no cross-lane movement between layers, rsn_field.hip).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -25,6 +26,34 @@ void rsn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* rsn_last_error(void) { return g_last_error.c_str(); }
+
+// CU count of the CURRENT device (256 on MI355X), cached per device ordinal: a process may drive several devices.
+int rsn_device_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cache[dev] == 0) {
+    int n = 0;
+    cache[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cache[dev];
+}
+
+int rsn_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v != nullptr && v[0] != '\0') ? atoi(v) : dflt;
+}
+
+// A/B switches of the tools (RSN_NO_PAIR=1 ...): read once per process and name.
+bool rsn_env_flag(const char* name) {
+  static thread_local const char* last_name = nullptr;
+  static thread_local bool last_val = false;
+  if (last_name == name) return last_val;  // call sites pass string literals: pointer identity is enough
+  const char* v = getenv(name);
+  last_name = name;
+  last_val = v != nullptr && v[0] != '\0' && v[0] != '0';
+  return last_val;
+}
 extern "C" int rsn_abi_version(void) { return RSN_ABI_VERSION; }
 
 int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {

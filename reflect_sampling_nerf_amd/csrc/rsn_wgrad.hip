@@ -327,15 +327,7 @@ static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0) {
   bool bf16 = mode == RSN_MMA_BF16 || mode == RSN_MMA_BF16X6;
   const long long total = a.seg_begin[a.n_seg];
   if (total == 0) return RSN_OK;
-  static int cached_cus = 0;
-  if (cached_cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cached_cus = n;
-    else
-      cached_cus = 256;
-  }
+  const int cached_cus = rsn_device_cus();
   // grid: every workgroup pays one atomic flush of the output tile (chip-wide ~1.3 TB/s of added bytes) and the
   // waves share the stages; T(G) = stages / (G * nsub) * t_stage + G * t_flush is smallest at G = sqrt(...)
   const int nkb = a.k_in > 128 ? 8 : (a.k_in > 64 ? 4 : 2), nkb_ = nkb;
