@@ -253,16 +253,19 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
         reducer.run_single_rank = True  # RSN_BENCH_FORCE_COLLECTIVE rehearsal
     batch = {"image": torch.rand(R, 3, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)}
     state = {"it": 100, "M": 0, "loss": None}  # past the 50-step loss warm-up: all eight loss terms are live
+    m_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # reflected rays, accumulated on the device: no host read per step
 
     def step(_i=None):
         state["loss"] = train_step(model, rb, batch, optimizer, reducer, state["it"], ray_chunk=args.ray_chunk or None)
         state["it"] += 1
-        state["M"] += int(getattr(model, "_last_num_reflected", 0))
+        nm = getattr(model, "_step_n_masked_dev", None)  # summed over the ray chunks by train_step
+        if nm is not None:
+            m_dev.add_(nm)
         dog.beat()
 
     for _ in range(warmup):
         step()
-    state["M"] = 0
+    m_dev.zero_()
     timer = ops.KernelTimer() if time_kernels else None
     torch.cuda.reset_peak_memory_stats()
     ops.TIMER = timer
@@ -270,6 +273,7 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
         elapsed = timed_region(dist, share, dev, steps, step)
     finally:
         ops.TIMER = None
+    state["M"] = int(m_dev.item())
     macs = algorithmic_macs(args.layers, args.width)
     rec = {"value": world * R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
            "warmup": warmup, "n_gpus": world, "loss": float(state["loss"]),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 12
+#define RSN_ABI_VERSION 13
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -343,6 +343,16 @@ int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const flo
 int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map,
                                float* dw, int32_t ld_dw, float* db, int32_t mma_mode, void* stream);
+
+/* The same with DEVICE-side segment lengths: segment s holds min(n_points_max[s], *n_dev[s] * per_count[s]) rows when
+ * n_dev[s] is not NULL (HOST array of device pointers to int32 counts; per_count = rows per counted unit, i.e. samples
+ * per ray), n_points_max[s] rows otherwise.  The reflect branch of a training step runs on the M rays behind the mask
+ * (reference model.py:229,259-290); M is produced on the device by rsn_reflect_setup and never read by the host, so the
+ * step has no device-to-host synchronisation.  The grid is sized for the upper bounds. */
+int rsn_weight_grad_multi_dev(int32_t n_segments, const int64_t* n_points_max, const int32_t* const* n_dev,
+                              const int32_t* per_count, const float* const* dy, int32_t ld_dy, int32_t n_out,
+                              const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map, float* dw,
+                              int32_t ld_dw, float* db, int32_t mma_mode, void* stream);
 
 /* rsn_colsum: out[c] (+)= sum_r x[r*ld + c], c < n_cols (bias gradients = column sums of dY). */
 int rsn_colsum(int64_t n_rows, int32_t n_cols, int32_t ld, const float* x, float* out, int32_t accumulate,

@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 12
+RSN_ABI_VERSION = 13
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -120,6 +120,9 @@ _SIGNATURES = {
     "rsn_weight_grad_multi_mode": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                              C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _fp, C.c_void_p, C.c_int32, _fp,
                                              C.c_int32, C.c_void_p]),
+    "rsn_weight_grad_multi_dev": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                            C.c_int32, _fp, C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_void_p]),
     "rsn_loss_forward_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp),
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_float), _fp,
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.c_void_p]),

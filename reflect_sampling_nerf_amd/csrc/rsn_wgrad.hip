@@ -25,7 +25,9 @@
 
 struct WGradArgs {
   int n_seg;
-  long long seg_begin[WG_MAX_SEG + 1];  // prefix sums of the segment lengths (points)
+  long long seg_begin[WG_MAX_SEG + 1];  // prefix sums of the segment lengths (points): upper bounds when n_dev is set
+  const int* n_dev[WG_MAX_SEG];         // optional device-side row count of segment s (rays), times ...
+  int per_count[WG_MAX_SEG];            // ... rows per count (samples per ray): n_s = min(bound, *n_dev * per_count)
   const float* dy[WG_MAX_SEG];          // [n_s, ld_dy]
   const float* x[WG_MAX_SEG];           // [n_s, ld_x]
   int ld_dy, ld_x, n_out, k_in, ld_dw;
@@ -241,7 +243,11 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   bool any = false;
 #pragma unroll 1
   for (int s = 0; s < a.n_seg; ++s) {
-    const long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
+    long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
+    if (a.n_dev[s]) {  // the reflected-ray count lives on the device (no host read in the training step): wave-uniform
+      const long long nd = (long long)(*a.n_dev[s]) * a.per_count[s];
+      n_s = nd < n_s ? (nd > 0 ? nd : 0) : n_s;
+    }
     const long long n_full = n_s / step;  // stages with every point in range
     const long long rem = n_s - n_full * step;
     const long long first = ((g - vprefix) % G + G) % G;  // this slot's first stage of the segment
@@ -380,7 +386,8 @@ static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0) {
 
 static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                   int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
-                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode);
+                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode,
+                                  const int32_t* const* n_dev = nullptr, const int32_t* per_count = nullptr);
 
 extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                      int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
@@ -390,7 +397,8 @@ extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points
 
 static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                   int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
-                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode) {
+                                  const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode,
+                                  const int32_t* const* n_dev, const int32_t* per_count) {
   RSN_REQUIRE(n_segments >= 0 && n_segments <= WG_MAX_SEG, RSN_ERR_INVALID_ARGUMENT, "n_segments=%d (at most %d)",
               n_segments, WG_MAX_SEG);
   RSN_REQUIRE(n_out >= 1 && n_out <= 256 && k_in >= 1 && k_in <= 256, RSN_ERR_INVALID_ARGUMENT,
@@ -408,6 +416,9 @@ static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, c
     a.dy[ns] = dy[s];
     a.x[ns] = x[s];
     a.seg_begin[ns + 1] = a.seg_begin[ns] + n_points[s];
+    a.n_dev[ns] = n_dev ? n_dev[s] : nullptr;
+    a.per_count[ns] = (n_dev && n_dev[s] && per_count) ? per_count[s] : 1;
+    RSN_REQUIRE(a.per_count[ns] >= 1, RSN_ERR_INVALID_ARGUMENT, "segment %d: per_count=%d", s, a.per_count[ns]);
     ++ns;
   }
   a.n_seg = ns;
@@ -423,6 +434,16 @@ extern "C" int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_p
   RSN_REQUIRE(mma_mode >= RSN_MMA_F32 && mma_mode <= RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "mma_mode %d", mma_mode);
   return weight_grad_multi_impl(n_segments, n_points, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream,
                                 mma_mode);
+}
+
+extern "C" int rsn_weight_grad_multi_dev(int32_t n_segments, const int64_t* n_points_max, const int32_t* const* n_dev,
+                                         const int32_t* per_count, const float* const* dy, int32_t ld_dy, int32_t n_out,
+                                         const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map,
+                                         float* dw, int32_t ld_dw, float* db, int32_t mma_mode, void* stream) {
+  RSN_REQUIRE(mma_mode >= RSN_MMA_F32 && mma_mode <= RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "mma_mode %d", mma_mode);
+  RSN_REQUIRE(n_segments == 0 || (n_dev && per_count), RSN_ERR_INVALID_ARGUMENT, "n_dev / per_count is NULL");
+  return weight_grad_multi_impl(n_segments, n_points_max, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream,
+                                mma_mode, n_dev, per_count);
 }
 
 extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x,

@@ -37,6 +37,8 @@ class KernelTimer:
             t["calls"] += 1
             t["ms"] += s.elapsed_time(e)
             for k, v in (work or {}).items():
+                if k.endswith("_dev"):  # [(device int tensor, multiplier)]: work that depends on a device-side count
+                    k, v = k[:-4], sum(int(c.item()) * m for c, m in v)
                 t["work"][k] = t["work"].get(k, 0) + v
         return out
 

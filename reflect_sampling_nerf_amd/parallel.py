@@ -152,12 +152,14 @@ def train_step(model, ray_bundle, batch, optimizer, reducer: Optional[FlatGradAl
     apply_loss_warmup(model, step)
     optimizer.zero_grad(set_to_none=True)
     R = ray_bundle.origins.shape[0]
+    n_masked = None  # reflected rays of the step, summed over the chunks ON THE DEVICE (model._step_n_masked_dev)
     if not ray_chunk or ray_chunk >= R:
         outputs = model(ray_bundle)
         loss_dict = model.get_loss_dict(outputs, batch)
         loss = sum(loss_dict.values())
         loss.backward()
         total = loss.detach()
+        n_masked = getattr(model, "_last_n_masked_dev", None)
     else:
         total = None
         for lo in range(0, R, ray_chunk):
@@ -168,7 +170,11 @@ def train_step(model, ray_bundle, batch, optimizer, reducer: Optional[FlatGradAl
             loss = sum(v * w if k in _MEAN_TERMS else v for k, v in loss_dict.items())
             loss.backward()
             total = loss.detach() if total is None else total + loss.detach()
+            nm = getattr(model, "_last_n_masked_dev", None)
+            if nm is not None:
+                n_masked = nm.clone() if n_masked is None else n_masked + nm
             del outputs, loss_dict, loss  # this chunk's activations are released before the next chunk's forward
+    model._step_n_masked_dev = n_masked
     if reducer is not None:
         reducer()
     optimizer.step()

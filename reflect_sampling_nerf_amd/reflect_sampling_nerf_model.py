@@ -119,12 +119,20 @@ class ReflectSamplingNeRFModel(Model):
         nears = ops._f32c(ray_bundle.nears.reshape(R))
         fars = ops._f32c(ray_bundle.fars.reshape(R))
         outs = GetOutputsTrain.apply(self, o, d, pa, nears, fars, jitter, bins, *self.field.parameters())
-        outputs = dict(zip(DIFF_KEYS, outs))
         aux = self._train_aux
         self._train_aux = None
+        outputs = type(aux)(zip(DIFF_KEYS, outs))  # LazyOutputs: depth_reflect_fine ([M, 1]) on first access
         for k, v in aux.items():
             outputs[k] = v.detach() if v.dtype.is_floating_point else v
+        outputs.lazy = aux.lazy
         return outputs
+
+    @property
+    def _last_num_reflected(self) -> int:
+        """M of the last training-mode get_outputs.  The count lives on the device (`_last_n_masked_dev`): reading it
+        here is a device-to-host synchronisation -- diagnostics only, the training step never does."""
+        nm = getattr(self, "_last_n_masked_dev", None)
+        return 0 if nm is None else int(nm.item())
 
     @torch.no_grad()
     def _get_outputs_eval(self, ray_bundle) -> Dict[str, Tensor]:

@@ -3,7 +3,7 @@
 
 forward  = samplers (stratified jitter) -> fused field kernels in training mode (activations saved, analytic
            normals by a dX sweep) -> compositing -> reflected rays (sized for R rays, the count M read from device memory
-           by every launch; the host awaits M once, behind the enqueued reflect levels).
+           by every launch; the host never reads it: the step has no device-to-host synchronisation).
 backward = the same pipeline reversed through librsn_hip.so: reflect combine / composite backward (suffix scan),
            rsn_field_backward_* (transposed-weight MFMA sweep producing every layer's pre-activation gradient),
            then rsn_weight_grad: dW = dY^T X and db for every linear layer (output-stationary MFMA reduction over
@@ -76,7 +76,7 @@ def _composite_backward(n, S, background, flags, detach_w, level, eb, weights, g
     if rough_samples is not None:
         out["g_rough"] = torch.empty(n, S, device=dev)
     if want_bg:
-        out["g_bg"] = torch.empty(n, 3, device=dev)
+        out["g_bg"] = torch.zeros(n, 3, device=dev)  # rows behind a device-side count stay zero
     io = CompositeBwdIO()
     io.sigma, io.euclid_bins, io.color, io.bg_rgb = ptr(level["sigma"]), ptr(eb), ptr(level["color"]), ptr(bg)
     io.roughness, io.weights, io.g_rgb, io.g_roughness = ptr(rough_samples), ptr(weights), ptr(g_rgb), ptr(g_rough)
@@ -148,61 +148,66 @@ _WGRAD_MODE = 0  # RSN_MMA_*: set per step by _weight_grads from the Field's MMA
 
 def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Optional[Tensor],
                  col_map: Optional[Tensor] = None):
-    """One rsn_weight_grad_multi launch: the reduction runs over the points of every (dy, x) segment (the field
-    evaluations of one step share their weights), so the per-launch flush is paid once per layer."""
+    """One weight-gradient launch: the reduction runs over the points of every (dy, x[, (count, rows per count)]) segment
+    (the field evaluations of one step share their weights), so the per-launch flush is paid once per layer.  A segment
+    with a device-side count holds min(rows of dy, count * rows per count) rows (rsn_weight_grad_multi_dev): the
+    reflected-ray count never comes to the host."""
     lib = _abi.load_library()
-    segs = [(dy, x) for dy, x in segs if dy.shape[0] > 0]
+    segs = [sg for sg in segs if sg[0].shape[0] > 0]
     if not segs:
         return
     ns = len(segs)
     ld_dy, ld_x = segs[0][0].stride(0), segs[0][1].stride(0)
-    assert all(dy.stride(0) == ld_dy and x.stride(0) == ld_x and dy.shape[0] == x.shape[0] for dy, x in segs)
-    npts = (C.c_int64 * ns)(*[dy.shape[0] for dy, _ in segs])
-    dys = (C.c_void_p * ns)(*[dy.data_ptr() for dy, _ in segs])
-    xs = (C.c_void_p * ns)(*[x.data_ptr() for _, x in segs])
+    assert all(sg[0].stride(0) == ld_dy and sg[1].stride(0) == ld_x and sg[0].shape[0] == sg[1].shape[0] for sg in segs)
+    npts = (C.c_int64 * ns)(*[sg[0].shape[0] for sg in segs])
+    dys = (C.c_void_p * ns)(*[sg[0].data_ptr() for sg in segs])
+    xs = (C.c_void_p * ns)(*[sg[1].data_ptr() for sg in segs])
+    cnt = [sg[2] if len(sg) > 2 else None for sg in segs]
+    ndev = (C.c_void_p * ns)(*[None if c is None else c[0].data_ptr() for c in cnt])
+    per = (C.c_int32 * ns)(*[1 if c is None else int(c[1]) for c in cnt])
     dwp = C.c_void_p(dw.data_ptr() + 4 * dw_col0)
-    ops.timed("weight_grad", {"point_out_in": sum(dy.shape[0] for dy, _ in segs) * n_out * k_in},
-              lambda: check(lib.rsn_weight_grad_multi_mode(ns, npts, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map), dwp,
-                                                           dw.stride(0), ptr(db), _WGRAD_MODE, ops._stream())))
+    work = {"point_out_in": sum(sg[0].shape[0] for sg in segs if len(sg) < 3 or sg[2] is None) * n_out * k_in}
+    dev_work = [(c[0], c[1] * n_out * k_in) for c in cnt if c is not None]
+    if dev_work:
+        work["point_out_in_dev"] = dev_work
+    ops.timed("weight_grad", work,
+              lambda: check(lib.rsn_weight_grad_multi_dev(ns, npts, ndev, per, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map),
+                                                          dwp, dw.stride(0), ptr(db), _WGRAD_MODE, ops._stream())))
 
 
 def _weight_grads(field, levels, acc: _GradAcc):
     """dW = dY^T X (+ db) for every linear layer, reduced over all field evaluations of the step at once.
-    levels: list of (saved activations, backward-sweep outputs, with_heads[, valid rows]).  Buffers of an evaluation that
-    was launched with a device-side ray count are sized for the upper bound: only their first `valid rows` rows exist."""
+    levels: list of (saved activations, backward-sweep outputs, with_heads[, (device count, rows per count)]).  Buffers of an
+    evaluation that was launched with a device-side ray count are sized for the upper bound; the weight-gradient kernel
+    reads the count itself and takes the first count * rows-per-count rows."""
     global _WGRAD_MODE
-    cut = []
-    for lv in levels:
-        sv, go, wh = lv[0], lv[1], lv[2]
-        nv = lv[3] if len(lv) > 3 else None
-        if nv is not None:
-            sv = {k: (v[:, :nv] if k in ("act", "relu_bits") else v[:nv]) for k, v in sv.items()}
-            go = {k: (v[:, :nv] if k == "dy" else v[:nv]) for k, v in go.items()}
-        cut.append((sv, go, wh))
-    levels = cut
     _WGRAD_MODE = int(field.mma_mode)  # bf16x6: split operands (fp32-equivalent); bf16: rounded operands (reduced precision)
     L, W = field.mlp_base.num_layers, field.width
     skip = field.field_desc().skip_layer
     enc_map, sh_map = field._enc_col_map, field._sh_col_map
     g = acc.g
+    cnt = [lv[3] if len(lv) > 3 else None for lv in levels]
+
+    def segs(pick, only_heads=False):
+        return [(*pick(lv[0], lv[1]), c) for lv, c in zip(levels, cnt) if lv[2] or not only_heads]
+
     for l in range(L):
         gw, gb = g[f"mlp_base.layers.{l}.weight"], g[f"mlp_base.layers.{l}.bias"]
         if l == 0:
-            _wgrad_multi([(go["dy"][l], sv["enc"]) for sv, go, _ in levels], W, ENC_SLOTS, gw, 0, gb, enc_map)
+            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["enc"])), W, ENC_SLOTS, gw, 0, gb, enc_map)
         elif l == skip:
-            _wgrad_multi([(go["dy"][l], sv["enc"]) for sv, go, _ in levels], W, ENC_SLOTS, gw, 0, gb, enc_map)
-            _wgrad_multi([(go["dy"][l], sv["act"][l - 1]) for sv, go, _ in levels], W, W, gw, 99, None)
+            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["enc"])), W, ENC_SLOTS, gw, 0, gb, enc_map)
+            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["act"][l - 1])), W, W, gw, 99, None)
         else:
-            _wgrad_multi([(go["dy"][l], sv["act"][l - 1]) for sv, go, _ in levels], W, W, gw, 0, gb)
-    emb = [(sv["act"][L - 1], go) for sv, go, _ in levels]
-    _wgrad_multi([(go["d_bott"], e) for e, go in emb], W, W, g["field_output_bottleneck.net.weight"], 0,
+            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["act"][l - 1])), W, W, gw, 0, gb)
+    _wgrad_multi(segs(lambda sv, go: (go["d_bott"], sv["act"][L - 1])), W, W, g["field_output_bottleneck.net.weight"], 0,
                  g["field_output_bottleneck.net.bias"])
-    _wgrad_multi([(go["da_mid"], sv["sh"]) for sv, go, _ in levels], 128, SH_SLOTS, g["mlp_mid.layers.0.weight"], 0,
+    _wgrad_multi(segs(lambda sv, go: (go["da_mid"], sv["sh"])), 128, SH_SLOTS, g["mlp_mid.layers.0.weight"], 0,
                  g["mlp_mid.layers.0.bias"], sh_map)
-    _wgrad_multi([(go["da_mid"], sv["bott"]) for sv, go, _ in levels], 128, W, g["mlp_mid.layers.0.weight"], 34, None)
-    _wgrad_multi([(go["dz_rgb"], sv["hid"]) for sv, go, _ in levels], 3, 128, g["field_output_mid.net.weight"], 0,
+    _wgrad_multi(segs(lambda sv, go: (go["da_mid"], sv["bott"])), 128, W, g["mlp_mid.layers.0.weight"], 34, None)
+    _wgrad_multi(segs(lambda sv, go: (go["dz_rgb"], sv["hid"])), 3, 128, g["field_output_mid.net.weight"], 0,
                  g["field_output_mid.net.bias"])
-    _wgrad_multi([(go["dz_heads"], sv["act"][L - 1]) for sv, go, wh in levels if wh], 16, W, acc.heads_w, 0, acc.heads_b)
+    _wgrad_multi(segs(lambda sv, go: (go["dz_heads"], sv["act"][L - 1]), only_heads=True), 16, W, acc.heads_w, 0, acc.heads_b)
 
 
 def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], need_input: bool, n_dev=None,
@@ -227,23 +232,50 @@ def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], ne
 
 def _ray_sum(x: Tensor, n: int, S: int, n_dev=None) -> Tensor:
     lib = _abi.load_library()
-    out = torch.empty(n, device=x.device)
+    out = torch.zeros(n, device=x.device)  # rows behind a device-side count stay zero
     check(lib.rsn_ray_sum(n, ptr(n_dev), S, ptr(x), ptr(out), ops._stream()))
     return out
 
 
-_MAILBOX: Dict[int, tuple] = {}
+class LazyOutputs(dict):
+    """The output dict of a training-mode get_outputs.  One key of the reference needs the reflected-ray count M on the
+    host: `depth_reflect_fine`, [M, 1], present only when M > 0 (model.py:341).  Here M lives on the device for the whole
+    step, so that entry is materialised on FIRST ACCESS (`d["depth_reflect_fine"]`, `"depth_reflect_fine" in d`,
+    `d.get(...)`, `d.materialise()`): one device-to-host read then, none for a training step that never looks at it
+    (get_loss_dict does not).  `keys()` / `items()` list it once it has been materialised."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.lazy: Dict[str, tuple] = {}
+
+    def _materialise(self, key):
+        count, per_ray = self.lazy.pop(key)
+        m = int(count.item())
+        if m > 0:
+            dict.__setitem__(self, key, per_ray[:m].unsqueeze(-1).detach())
+
+    def materialise(self):
+        for key in list(self.lazy):
+            self._materialise(key)
+        return self
+
+    def __missing__(self, key):
+        if key in self.lazy:
+            self._materialise(key)
+            if dict.__contains__(self, key):
+                return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        if key in self.lazy:
+            self._materialise(key)
+        return dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
 
 
-def _count_mailbox(dev):
-    """(pinned int32[1], event) per device: where the reflected-ray count lands on the host.  Module state, not model
-    state: a model stays free of pinned memory and of HIP events (deepcopy, pickling by the host framework)."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    box = _MAILBOX.get(key)
-    if box is None:
-        box = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
-        _MAILBOX[key] = box
-    return box
+_LazyAux = LazyOutputs
 
 
 # ------------------------------------------------------------------------------------------------ the autograd node
@@ -315,20 +347,15 @@ class GetOutputsTrain(torch.autograd.Function):
         cf = ops.composite(R, None, Sf, 1, CLIP, lf["sigma"], eb_f, lf["color"], level=lf, surface=True)
         rs = ops.reflect_setup(o, d, cf["accumulation"], cf["depth"], cf["normals"], cf["roughness"], float(model.far))
         # C.-F. the reflect branch runs on the M <= R rays behind the mask.  Like the eval path (model.get_outputs) every
-        # launch is sized for R rays and takes the count from device memory (rs["n_masked"]): the host reads M only AFTER the
-        # whole branch is enqueued (it needs it for the [M, 1] output and for the weight-gradient segment lengths), so the
-        # read overlaps the reflect levels instead of idling the GPU between the fine level and the first reflect launch.
+        # launch is sized for R rays and takes the count from device memory (rs["n_masked"]).  The host never reads M: the
+        # [M, 1] output is materialised on demand (LazyOutputs) and the weight-gradient kernel takes its segment lengths
+        # from the same device word, so the host runs ahead of the GPU across the whole step (and into the next one).
         nm = rs["n_masked"]
         lib = _abi.load_library()
         W, L = fld.width, fld.mlp_base.num_layers
-        # injected draws / bins come in the reference's shapes ([M, S + 1]): that mode reads M first
+        # injected draws / bins come in the reference's shapes ([M, S + 1]): that (test) mode reads M first.  The
+        # production path never does: M stays on the device for the whole step -- forward, backward, weight gradients.
         M = int(nm.item()) if (jitter or bins) else None
-        if M is None:
-            # the copy of the count is ISSUED here, right behind reflect_setup, into pinned host memory, and awaited (event)
-            # after the reflect levels are enqueued: the wait ends when the GPU has passed this point, not the levels
-            nm_host, nm_event = _count_mailbox(dev)
-            nm_host.copy_(nm, non_blocking=True)
-            nm_event.record()
         o2, d2, pa2, sq = rs["origins2"], rs["directions2"], rs["pixel_area2"], rs["sqradius"]
         near2, far2 = rs["nears2"], rs["fars2"]
         f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
@@ -339,7 +366,8 @@ class GetOutputsTrain(torch.autograd.Function):
         desc = fld.field_desc()
         fs = _saved_struct(inf_saved)
         pk = fld.packed_weights()
-        work_inf, work_rc, work_rf = {"points": 0}, {"points": 0}, {"points": 0}
+        # launches sized for R rays do the work of M: the timer resolves the device-side count when it reads its events
+        work_inf, work_rc, work_rf = ({"points": 0, "points_dev": [(nm, k)]} for k in (1, Src, Srf))
         ops.timed("field_forward_train", work_inf, lambda: check(
             lib.rsn_field_forward_inf_train(C.byref(desc), ptr(pk), R, ptr(nm), ptr(d2), ptr(sq), ptr(bg), C.byref(fs),
                                             ops._stream())))
@@ -355,26 +383,28 @@ class GetOutputsTrain(torch.autograd.Function):
         crf = ops.composite(R, nm, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
         ops.reflect_combine(R, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
         mask_bool = rs["mask"].bool()
-        if M is None:
-            nm_event.synchronize()  # the step's one host wait; the reflect levels are already queued behind it
-            M = int(nm_host[0])
-        work_inf["points"], work_rc["points"], work_rf["points"] = M, M * Src, M * Srf
-        model._last_num_reflected = M
+        model._last_n_masked_dev = nm  # device-side; `model._last_num_reflected` reads it on demand (a host sync)
 
-        aux = {
+        aux = _LazyAux({
             "accumulation_coarse": cc["accumulation"].unsqueeze(-1), "accumulation_fine": cf["accumulation"].unsqueeze(-1),
             "depth_coarse": cc["depth"].unsqueeze(-1), "depth_fine": cf["depth"].unsqueeze(-1),
             "weights_coarse": cc["weights"].unsqueeze(-1), "weights_fine": cf["weights"].unsqueeze(-1),
             "normals_coarse": lc["normals"], "normals_fine": lf["normals"],
             "diff": cf["diff"], "tint": cf["tint"], "mask": mask_bool,
-        }
-        st = dict(R=R, M=M, eb_c=eb_c, eb_f=eb_f, lc=lc, lf=lf, cc=cc, cf=cf, rs=rs, rays=(o, d, pa))
-        if M > 0:
+        })
+        # [M, 1] (reference model.py:341, present only when M > 0): its shape needs M on the host, so it is materialised on
+        # first access -- the training step itself never asks for it
+        if M is None:
+            aux.lazy["depth_reflect_fine"] = (nm, crf["depth"])
+        elif M > 0:  # the count is on the host already (injected draws / bins)
             aux["depth_reflect_fine"] = crf["depth"][:M].unsqueeze(-1)
-            st.update(rays2=(o2, d2, pa2), sq=sq, bg=bg, inf_saved=inf_saved, eb_rc=eb_rc, eb_rf=eb_rf, lrc=lrc, lrf=lrf,
-                      crc=crc, crf=crf)
+        st = dict(R=R, eb_c=eb_c, eb_f=eb_f, lc=lc, lf=lf, cc=cc, cf=cf, rs=rs, rays=(o, d, pa),
+                  rays2=(o2, d2, pa2), sq=sq, bg=bg, inf_saved=inf_saved, eb_rc=eb_rc, eb_rf=eb_rf, lrc=lrc, lrf=lrf,
+                  crc=crc, crf=crf)
         if getattr(model, "_keep_train_state", False):  # test hook: the sample positions this pass evaluated
-            exp = dict(st, sb_c=sb_c, sb_f=sb_f)
+            if M is None:
+                M = int(nm.item())
+            exp = dict(st, M=M, sb_c=sb_c, sb_f=sb_f)
             if M > 0:  # the reflect levels' buffers are sized for R rays: the hook shows their M real rows
                 def trim(lv, n):
                     sv = {k: (v[:, :n] if k in ("act", "relu_bits") else v[:n]) for k, v in lv["saved"].items()}
@@ -395,7 +425,7 @@ class GetOutputsTrain(torch.autograd.Function):
         st, model = ctx.st, ctx.model
         fld = model.field
         lib = _abi.load_library()
-        R, M = st["R"], st["M"]
+        R = st["R"]
         dev = st["rays"][0].device
         CLIP = ops.RSN_COMP_CLIP_RGB
         cfg = model.config
@@ -405,41 +435,42 @@ class GetOutputsTrain(torch.autograd.Function):
         g_rgb_c, g_rgb_f = z(g_rgb_c, R, 3), z(g_rgb_f, R, 3)
         g_refl_c, g_refl_f = z(g_refl_c, R, 3), z(g_refl_f, R, 3)
         acc = _GradAcc(fld)
-        pending = []  # (saved, gout, with_heads) of every field evaluation: weight gradients in one pass at the end
+        pending = []  # (saved, gout, with_heads[, device count]) of every field evaluation: weight gradients at the end
         cf, rs = st["cf"], st["rs"]
         g_rough_ray = z(g_rough, R, 1).reshape(R).clone()
 
-        if M > 0:
-            # everything of the reflect branch is sized for R rays and launched with the device-side count (see forward);
-            # the weight gradients take the first M (x samples) rows
-            nm = rs["n_masked"]
-            g_bg = torch.zeros(R, 3, device=dev)
-            g_pa2 = torch.zeros(R, device=dev)
-            for eb, lv, cp, g_out, S in ((st["eb_rf"], st["lrf"], st["crf"], g_refl_f, Srf),
-                                         (st["eb_rc"], st["lrc"], st["crc"], g_refl_c, Src)):
-                g_comp = torch.empty(R, 3, device=dev)
-                check(lib.rsn_reflect_combine_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(cf["diff"]), ptr(cf["tint"]),
-                                                       ptr(cp["rgb"]), ptr(g_out), ptr(g_comp), ops._stream()))
-                cb = _composite_backward(R, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
-                                         want_bg=True, n_dev=nm)
-                g_bg[:M] += cb["g_bg"][:M]
-                gout = _field_backward(fld, st["rays2"], eb, lv, {"color": cb["g_color"]}, need_input=True, n_dev=nm,
-                                       work={"points": M * S})
-                g_pa2[:M] += _ray_sum(gout["d_input"], R, S, nm)[:M]
-                pending.append((lv["saved"], gout, True, M * S))
-            # get_inf_color
-            gout, gst = _alloc_gout(fld, R, dev, True)
-            desc = fld.field_desc()
-            fs = _saved_struct(st["inf_saved"])
-            pk = fld.packed_weights()
-            ops.timed("field_backward_input", {"points": M}, lambda: check(
-                lib.rsn_field_backward_inf(C.byref(desc), ptr(pk), R, ptr(nm), ptr(st["rays2"][1]), ptr(st["sq"]),
-                                           C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream())))
-            pending.append((st["inf_saved"], gout, False, M))
-            g_r = torch.empty(R, device=dev)
-            check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
-                                           ptr(gout["d_input"]), ptr(g_pa2), ptr(g_r), ops._stream()))
-            g_rough_ray += g_r
+        # The reflect branch: everything is sized for R rays and launched with the device-side count M = rs["n_masked"]
+        # (see forward); rows M.. of the per-ray buffers are zero-filled so that whole-buffer sums are sums over M rows, and
+        # the weight-gradient kernel takes the first M (x samples) rows of each reflect evaluation by the same count.  With
+        # M = 0 every launch below is a no-op on the device: no host-side early-out, no host read.
+        nm = rs["n_masked"]
+        g_bg = torch.zeros(R, 3, device=dev)
+        g_pa2 = torch.zeros(R, device=dev)
+        for eb, lv, cp, g_out, S in ((st["eb_rf"], st["lrf"], st["crf"], g_refl_f, Srf),
+                                     (st["eb_rc"], st["lrc"], st["crc"], g_refl_c, Src)):
+            g_comp = torch.empty(R, 3, device=dev)
+            check(lib.rsn_reflect_combine_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(cf["diff"]), ptr(cf["tint"]),
+                                                   ptr(cp["rgb"]), ptr(g_out), ptr(g_comp), ops._stream()))
+            cb = _composite_backward(R, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
+                                     want_bg=True, n_dev=nm)
+            g_bg += cb["g_bg"]
+            gout = _field_backward(fld, st["rays2"], eb, lv, {"color": cb["g_color"]}, need_input=True, n_dev=nm,
+                                   work={"points": 0, "points_dev": [(nm, S)]})
+            g_pa2 += _ray_sum(gout["d_input"], R, S, nm)
+            pending.append((lv["saved"], gout, True, (nm, S)))
+        # get_inf_color
+        gout, gst = _alloc_gout(fld, R, dev, True)
+        desc = fld.field_desc()
+        fs = _saved_struct(st["inf_saved"])
+        pk = fld.packed_weights()
+        ops.timed("field_backward_input", {"points": 0, "points_dev": [(nm, 1)]}, lambda: check(
+            lib.rsn_field_backward_inf(C.byref(desc), ptr(pk), R, ptr(nm), ptr(st["rays2"][1]), ptr(st["sq"]),
+                                       C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream())))
+        pending.append((st["inf_saved"], gout, False, (nm, 1)))
+        g_r = torch.empty(R, device=dev)  # the kernel zero-fills the rays that are not reflected
+        check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
+                                       ptr(gout["d_input"]), ptr(g_pa2), ptr(g_r), ops._stream()))
+        g_rough_ray += g_r
 
         # fine primary level (+ the live accumulation of the non-reflected rays' default reflect colour)
         lf = st["lf"]

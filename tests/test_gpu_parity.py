@@ -1041,8 +1041,8 @@ def test_pdf_sampler_degenerate_histograms(dev, kind, tan, near, far):
 
 
 @pytest.mark.parametrize("name", ["trainstep_l8_w64", "trainstep_l8_w256", "trainstep_l4_w128"])
-@pytest.mark.parametrize("inject_bins", [True, False])
-def test_train_step_against_reference_fixture(dev, name, inject_bins):
+@pytest.mark.parametrize("inject_bins,mma", [(True, "f32"), (False, "f32"), (True, "bf16x6")])
+def test_train_step_against_reference_fixture(dev, name, inject_bins, mma):
     """One whole training step of the REFERENCE itself (tests/golden/trainstep_*.npz: get_outputs in train mode, its
     own get_loss_dict, backward; generated by oracle/make_golden.py) against the HIP path with the reference's
     parameters, rays, logged jitter and target image: outputs, the eight loss terms, every parameter gradient.
@@ -1051,7 +1051,9 @@ def test_train_step_against_reference_fixture(dev, name, inject_bins):
     HIP samplers' results, so both pipelines evaluate IDENTICAL sample positions -> EVERY parameter gradient must be
     within 2e-4 of the tensor's largest entry.  inject_bins=False is the free-running pipeline (its own PDF
     resampling, ~1e-6 from the reference's): tight everywhere above the skip layer, direction + 5 % below it (a few
-    ulp-wide resampled bins flip near-zero ReLU units of the two encoding-consuming layers)."""
+    ulp-wide resampled bins flip near-zero ReLU units of the two encoding-consuming layers).
+    mma="bf16x6": the fp32-equivalent split-bf16 mode (forward, sweeps, weight gradients) meets the SAME bounds on the
+    reference's logged bins."""
     meta, g = load_golden(name)
     s = meta["samples"]
     cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=s[0], num_importance_samples=s[1],
@@ -1060,6 +1062,7 @@ def test_train_step_against_reference_fixture(dev, name, inject_bins):
     model = cfg.setup(scene_box=None, num_train_data=1)
     model.field.load_state_dict(g["param"])
     model.to(dev).train()
+    model.field.set_mma_mode(mma)
     assert dict(model.config.loss_coefficients) == pytest.approx(meta["loss_coefficients"])
     i = g["in"]
     rb = pkg.RayBundle(origins=i["origins"].to(dev), directions=i["directions"].to(dev),
@@ -1107,8 +1110,179 @@ def test_train_step_against_reference_fixture(dev, name, inject_bins):
             assert cos >= 0.999 and rel <= 5e-2, f"{name_p}: cos {cos:.6f} rel-L2 {rel:.3e}"
         else:
             assert rel <= 5e-4, f"{name_p}: rel-L2 {rel:.3e}"
-    print(f"{name} inject_bins={inject_bins}: worst gradient error / tensor max "
+    print(f"{name} inject_bins={inject_bins} mma={mma}: worst gradient error / tensor max "
           f"{max(r[1] for r in report):.2e} ({max(report, key=lambda r: r[1])[0]})")
+
+
+# ---------------------------------------------------------------------------------------------- the step without host reads
+def _train_setup(dev, R, samples, layers=8, width=128, bias_shift=2.0, seed=0):
+    torch.manual_seed(seed)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=samples[0], num_importance_samples=samples[1],
+                                            num_reflect_coarse_samples=samples[2], num_reflect_importance_samples=samples[3],
+                                            base_mlp_num_layers=layers, base_mlp_layer_width=width)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += bias_shift
+    model.to(dev).train()
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=seed)
+    rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.to(dev),
+                       nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev))
+    batch = {"image": torch.rand(R, 3, generator=torch.Generator().manual_seed(seed + 1)).to(dev)}
+    return model, rb, batch
+
+
+def test_training_step_issues_no_device_to_host_read(dev):
+    """The reflected-ray count M (reference model.py:229,259: a host-side `mask.any()` / boolean gather) stays on the device
+    for the whole optimisation step -- forward, loss, backward, weight gradients (their segment lengths are device-side),
+    RAdam.  torch's sync debug mode turns any implicit device-to-host synchronisation into an error."""
+    from reflect_sampling_nerf_amd.parallel import train_step
+
+    model, rb, batch = _train_setup(dev, 192, (24, 24, 16, 16))
+    opt = pkg.FusedRAdam(model.get_param_groups()["fields"], lr=1e-3, eps=1e-15)
+    train_step(model, rb, batch, opt, None, 100)  # warm-up: one-time uploads (coefficient tensor, column maps, pack table)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for k in range(3):
+            loss = train_step(model, rb, batch, opt, None, 101 + k)
+            outputs = model(rb)  # a bare forward too: the lazy [M, 1] entry must not be touched by building the dict
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert bool(torch.isfinite(loss))
+    M = model._last_num_reflected  # reading it is the (explicit) host read
+    assert 0 < M <= 192
+    assert outputs["depth_reflect_fine"].shape == (M, 1) and "depth_reflect_fine" in outputs.keys()
+
+
+def test_train_step_without_reflected_rays(dev):
+    """M == 0 in TRAINING mode (the reference returns early, model.py:259-260): every reflect launch runs on a device-side
+    count of zero, backward included.  Reflect colours are white * (1 - acc_fine) (model.py:240-241), every parameter
+    still receives a finite gradient (the default reflect colour carries the live accumulation), nothing is NaN."""
+    model, rb, batch = _train_setup(dev, 160, (16, 16, 8, 8), bias_shift=-12.0)
+    out = model(rb)
+    assert int(out["mask"].sum()) == 0 and model._last_num_reflected == 0
+    assert "depth_reflect_fine" not in out
+    white = 1.0 - out["accumulation_fine"]
+    for k in ("mid_reflect_coarse", "mid_reflect_fine"):
+        assert max_abs(out[k].detach().cpu(), white.expand(-1, 3).cpu()) <= 1e-6, k
+    sum(model.get_loss_dict(out, batch).values()).backward()
+    torch.cuda.synchronize()
+    for name, p in model.field.named_parameters():
+        if "field_output_low" in name:
+            assert p.grad is None
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+    # and against the oracle on shared draws: the same early-out (no reflected ray on either side), the same outputs
+    P = {k: v.detach().cpu() for k, v in model.field.state_dict().items()}
+    fs, ms = cpu_ref.FieldSpec(num_layers=8, width=128), cpu_ref.ModelSpec(16, 16, 8, 8)
+    g = torch.Generator().manual_seed(9)
+    jit = {"coarse": torch.rand(160, 17, generator=g), "fine": torch.rand(160, 17, generator=g)}
+    model.zero_grad(set_to_none=True)
+    out = model._get_outputs_train(rb, jitter={k: v.to(dev) for k, v in jit.items()})
+    ref = cpu_ref.get_outputs(P, fs, ms, rb.origins.cpu(), rb.directions.cpu(), rb.pixel_area.cpu(), rb.nears.cpu(),
+                              rb.fars.cpu(), training=True, jitter=jit)  # (autograd normals: no no_grad around it)
+    assert int(ref["mask"].sum()) == 0 and "depth_reflect_fine" not in ref
+    for k in ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "accumulation_fine"):
+        assert max_abs(out[k].detach().cpu(), ref[k].detach()) <= TOL, k
+
+
+def test_device_counted_step_equals_host_counted_step(dev, monkeypatch):
+    """Production path (no draws injected: every reflect launch and the weight-gradient segments take M from device
+    memory) against the test path (draws injected: M read on the host, reflect draws gathered per reflected ray), with
+    torch.rand pinned to one constant so that both see the same draws: identical outputs, and parameter gradients equal
+    up to the order of the fp32 atomics of the weight-gradient flush."""
+    R, samples = 224, (24, 40, 16, 24)
+    model, rb, batch = _train_setup(dev, R, samples, layers=8, width=64)
+    const = 0.37
+
+    def fake_rand(*shape, **kw):
+        kw.pop("generator", None)
+        return torch.full(tuple(shape), const, **kw)
+
+    def run(inject):
+        model.zero_grad(set_to_none=True)
+        jit = None
+        if inject:
+            jit = {k: torch.full((R, s + 1), const, device=dev) for k, s in
+                   zip(("coarse", "fine", "reflect_coarse", "reflect_fine"), samples)}
+        out = model._get_outputs_train(rb, jitter=jit)
+        sum(model.get_loss_dict(out, batch).values()).backward()
+        torch.cuda.synchronize()
+        return out, {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None}
+
+    monkeypatch.setattr(torch, "rand", fake_rand)
+    out_d, g_d = run(False)
+    out_h, g_h = run(True)
+    monkeypatch.undo()
+    M = int(out_h["mask"].sum())
+    assert 0 < M < R
+    assert sorted(out_d.materialise().keys()) == sorted(out_h.keys())
+    for k in out_h:
+        assert torch.equal(out_d[k], out_h[k]), k
+    assert sorted(g_d) == sorted(g_h)
+    for n in g_h:
+        scale = float(g_h[n].abs().max()) + 1e-30
+        assert float((g_d[n] - g_h[n]).abs().max()) <= 2e-6 * scale, n
+
+
+def test_headline_workload_properties(dev):
+    """The headline workload itself (bench.py default, BASELINE metric: 4096 rays x (128 coarse + 128 fine) + reflect
+    64 + 64, 8 x 256, training step): size-independent properties of the full-size step."""
+    from reflect_sampling_nerf_amd.parallel import train_step
+
+    R = 4096
+    model, rb, batch = _train_setup(dev, R, (128, 128, 64, 64), layers=8, width=256)
+    params = model.get_param_groups()["fields"]
+    opt = pkg.FusedRAdam(params, lr=1e-3, eps=1e-15, lr_final=1e-4, max_steps=50000)
+    out = model(rb)
+    M = int(out["mask"].sum())
+    assert 0 < M < R and model._last_num_reflected == M
+    for lvl in ("coarse", "fine"):
+        w = out[f"weights_{lvl}"][..., 0]
+        assert float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-5
+        assert max_abs(w.sum(-1, keepdim=True), out[f"accumulation_{lvl}"]) <= 1e-5
+        assert float((out[f"normals_{lvl}"].norm(dim=-1) - 1).abs().max()) <= 1e-4
+        assert float((out[f"pred_normals_{lvl}"].norm(dim=-1) - 1).abs().max()) <= 1e-4
+        rgb = out[f"mid_rgb_{lvl}"]
+        assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
+    # rays that are not reflected keep white * (1 - acc_fine) (model.py:240-241); reflected ones are clipped colours
+    keep = ~out["mask"]
+    white = (1.0 - out["accumulation_fine"]).expand(-1, 3)
+    for k in ("mid_reflect_coarse", "mid_reflect_fine"):
+        assert max_abs(out[k][keep], white[keep]) <= 1e-6
+        assert float(out[k].min()) >= 0.0 and float(out[k].max()) <= 1.0 + 1e-6
+    assert out["depth_reflect_fine"].shape == (M, 1)
+    loss = sum(model.get_loss_dict(out, batch).values())
+    loss.backward()
+    for name, p in model.field.named_parameters():
+        if "field_output_low" in name:
+            assert p.grad is None
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0.0, name
+    # linearity of the backward pass in the upstream gradient: 2 x loss -> 2 x every gradient (weight-gradient atomics
+    # reorder the sums: 2e-5 of the tensor maximum)
+    g1 = {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(7)
+    o1 = model(rb)
+    torch.manual_seed(7)
+    o2 = model(rb)
+    for k in ("mid_rgb_fine", "mid_reflect_fine", "weights_fine"):
+        assert torch.equal(o1[k], o2[k]), k  # same draws -> bit-identical forward
+    (2.0 * sum(model.get_loss_dict(o2, batch).values())).backward()
+    del o1
+    torch.manual_seed(7)
+    g2 = {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    sum(model.get_loss_dict(model(rb), batch).values()).backward()
+    for n, p in model.field.named_parameters():
+        if p.grad is not None:
+            scale = float(p.grad.abs().max()) + 1e-30
+            assert float((g2[n] - 2.0 * p.grad).abs().max()) <= 4e-5 * scale, n
+    # a few optimiser steps: finite, every trained tensor moves, the loss of the SAME batch goes down
+    losses = [float(train_step(model, rb, batch, opt, None, 100 + k)) for k in range(4)]
+    assert all(x == x and abs(x) < float("inf") for x in losses) and losses[-1] < losses[0]
+    assert all(bool(torch.isfinite(p).all()) for p in params) and g1
 
 
 # ---------------------------------------------------------------------------------------------- BASELINE configurations
