@@ -180,6 +180,13 @@ typedef struct rsn_field_grads_in {
   const float* pred_normals; /* [N,3] d loss / d pred_normals (predicted-normal loss, model.py:403-404) */
   const float* n_dot_d;      /* [N]   d loss / d n_dot_d       (orientation loss, model.py:406-407)  */
   const float* roughness;    /* [N]   d loss / d sigmoid(roughness head) (rendered roughness, model.py:225-226) */
+  /* fused normal losses: upstream gradients PER RAY of rsn_composite_io.pn_loss_ray / ori_loss_ray; the kernel forms
+   * d/d pred_normals = ray_pn_loss[r] w (-2)(normals - pred_normals) and d/d n_dot_d = ray_ori_loss[r] w 2 max(0, n_dot_d)
+   * itself from the level's weights, analytic normals (rsn_field_saved.normals) and forward outputs (pred_normals,
+   * n_dot_d), so the per-sample gradient tensors never exist.  Added to pred_normals / n_dot_d above when both are given. */
+  const float* ray_pn_loss;  /* [R] or NULL */
+  const float* ray_ori_loss; /* [R] or NULL */
+  const float* weights;      /* [N] compositing weights of the level (needed by the two above) */
 } rsn_field_grads_in;
 
 /* Pre-activation gradients of every linear layer, row-major, consumed by the weight-gradient GEMMs
@@ -276,6 +283,15 @@ typedef struct rsn_composite_io {
   float* tint_out;
   float* normals_out;
   float* roughness_out;
+  /* training: the per-sample loss terms of get_loss_dict (reflect_sampling_nerf_model.py:395-407) reduced per ray in the
+   * compositing epilogue, where the weights are in registers:
+   *   pn_loss_ray[r]  = sum_s w |normals - pred_normals|^2      (predicted_normal_loss_*: the sum over r)
+   *   ori_loss_ray[r] = sum_s w max(0, n_dot_d)^2               (orientation_loss_*)
+   * normals = the analytic normals of the training forward (rsn_field_saved.normals); all NULL = skip. */
+  const float* normals;      /* [R,S,3] or NULL */
+  const float* n_dot_d;      /* [R,S] or NULL */
+  float* pn_loss_ray;        /* [R] or NULL (needs normals and pred_normals) */
+  float* ori_loss_ray;       /* [R] or NULL (needs n_dot_d) */
 } rsn_composite_io;
 
 #define RSN_COMP_EVAL 1
@@ -353,6 +369,18 @@ int rsn_weight_grad_multi_dev(int32_t n_segments, const int64_t* n_points_max, c
                               const int32_t* per_count, const float* const* dy, int32_t ld_dy, int32_t n_out,
                               const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map, float* dw,
                               int32_t ld_dw, float* db, int32_t mma_mode, void* stream);
+
+/* get_loss_dict on per-ray quantities only (training step: the per-sample normal terms arrive reduced per ray from
+ * rsn_composite): losses8[k] = the UNSCALED terms (0-3 MSE means of rgb4[k] against image; 4,5 = sum_r pn_loss_ray2[lv][r];
+ * 6,7 = sum_r ori_loss_ray2[lv][r]); g_rgb4[k] = coef8[k] * d term / d rgb4[k]. */
+int rsn_loss_rays_forward(int32_t n_rays, const float* image, const float* const* rgb4, const float* const* pn_loss_ray2,
+                          const float* const* ori_loss_ray2, const float* coef8, float* losses8, float* const* g_rgb4,
+                          void* stream);
+
+/* its chain rule: g_rgb4[k] *= upstream8[k] in place; g_pn_ray2[lv][r] = coef8[4+lv] * upstream8[4+lv],
+ * g_ori_ray2[lv][r] = coef8[6+lv] * upstream8[6+lv] (upstream8: DEVICE pointer). */
+int rsn_loss_rays_backward(int32_t n_rays, const float* upstream8, const float* coef8, float* const* g_rgb4,
+                           float* const* g_pn_ray2, float* const* g_ori_ray2, void* stream);
 
 /* rsn_colsum: out[c] (+)= sum_r x[r*ld + c], c < n_cols (bias gradients = column sums of dY). */
 int rsn_colsum(int64_t n_rows, int32_t n_cols, int32_t ld, const float* x, float* out, int32_t accumulate,

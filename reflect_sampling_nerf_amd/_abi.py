@@ -57,7 +57,8 @@ class FieldSaved(C.Structure):
 
 
 class FieldGradsIn(C.Structure):
-    _fields_ = [(n, _fp) for n in ("sigma", "color", "pred_normals", "n_dot_d", "roughness")]
+    _fields_ = [(n, _fp) for n in ("sigma", "color", "pred_normals", "n_dot_d", "roughness", "ray_pn_loss", "ray_ori_loss",
+                                   "weights")]
 
 
 class FieldGradsOut(C.Structure):
@@ -73,7 +74,8 @@ class CompositeBwdIO(C.Structure):
 class CompositeIO(C.Structure):
     _fields_ = [(n, _fp) for n in
                 ("sigma", "euclid_bins", "color", "bg_rgb", "diff", "tint", "pred_normals", "roughness",
-                 "weights", "rgb", "accumulation", "depth", "diff_out", "tint_out", "normals_out", "roughness_out")]
+                 "weights", "rgb", "accumulation", "depth", "diff_out", "tint_out", "normals_out", "roughness_out",
+                 "normals", "n_dot_d", "pn_loss_ray", "ori_loss_ray")]
 
 
 class ReflectIO(C.Structure):
@@ -126,6 +128,10 @@ _SIGNATURES = {
     "rsn_loss_forward_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp),
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_float), _fp,
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.c_void_p]),
+    "rsn_loss_rays_forward": (C.c_int, [C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_float),
+                                        _fp, C.POINTER(_fp), C.c_void_p]),
+    "rsn_loss_rays_backward": (C.c_int, [C.c_int32, _fp, C.POINTER(C.c_float), C.POINTER(_fp), C.POINTER(_fp),
+                                         C.POINTER(_fp), C.c_void_p]),
     "rsn_loss_scale_grads": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp),
                                        C.c_void_p]),
     "rsn_radam_step": (C.c_int, [C.c_int32, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp),

@@ -198,11 +198,20 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) G[c] = a.gin.pred_normals[pc * 3 + c] * live;
           }
-          if (a.gin.n_dot_d) {
-            const float gd = a.gin.n_dot_d[pc] * live;
+          float gd = a.gin.n_dot_d ? a.gin.n_dot_d[pc] * live : 0.0f;
+          if (a.gin.ray_pn_loss || a.gin.ray_ori_loss) {
+            // fused normal losses (model.py:403-407): per-ray upstream gradients of sum_s w |n - n_pred|^2 and
+            // sum_s w max(0, n.d)^2; the per-sample gradients are formed here and never stored
+            const float w = a.gin.weights[pc] * live;
+            if (a.gin.ray_pn_loss) {
+              const float gw = a.gin.ray_pn_loss[ray] * w * -2.0f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) G[c] += gd * dir[c];
+              for (int c = 0; c < 3; ++c) G[c] += gw * (a.saved.normals[pc * 3 + c] - a.fwd.pred_normals[pc * 3 + c]);
+            }
+            if (a.gin.ray_ori_loss) gd += a.gin.ray_ori_loss[ray] * w * (2.0f * fmaxf(a.fwd.n_dot_d[pc], 0.0f));
           }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) G[c] += gd * dir[c];
           const float nraw[3] = {hd.x, hd.y, hd.z};
           const float len = fmaxf(sqrtf(nraw[0] * nraw[0] + nraw[1] * nraw[1] + nraw[2] * nraw[2]), 1e-12f);
           const float v[3] = {-(nraw[0] / len), -(nraw[1] / len), -(nraw[2] / len)};
@@ -310,6 +319,11 @@ static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
               "need_input_grad needs saved.enc and gout.d_input");
   RSN_REQUIRE(a.mode == RSN_MODE_INF || (a.fwd.raw_density && a.fwd.diff && a.fwd.tint), RSN_ERR_INVALID_ARGUMENT,
               "forward values raw_density/diff/tint are required");
+  RSN_REQUIRE(!(a.gin.ray_pn_loss || a.gin.ray_ori_loss) || (a.mode == RSN_MODE_FRUSTUM && a.gin.weights),
+              RSN_ERR_INVALID_ARGUMENT, "fused normal losses need the level's weights (frustum levels only)");
+  RSN_REQUIRE(!a.gin.ray_pn_loss || (a.saved.normals && a.fwd.pred_normals), RSN_ERR_INVALID_ARGUMENT,
+              "ray_pn_loss needs saved.normals and the forward pred_normals");
+  RSN_REQUIRE(!a.gin.ray_ori_loss || a.fwd.n_dot_d, RSN_ERR_INVALID_ARGUMENT, "ray_ori_loss needs the forward n_dot_d");
   a.num_layers = d->num_layers;
   a.skip_layer = d->skip_layer;
   a.density_bias = d->density_bias;

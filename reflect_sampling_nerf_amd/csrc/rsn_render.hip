@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void rsn_composite_kernel(int n_rays, const in
     float acc = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, t0s = 0.0f, t1s = 0.0f, t2s = 0.0f;
     float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, rs = 0.0f;
+    float pl = 0.0f, ol = 0.0f;  // per-ray partials of the normal losses (model.py:403-407)
     int median_idx = -1;
     for (int base = 0; base < S; base += 64) {
       const int i = base + lane;
@@ -255,7 +256,16 @@ __global__ __launch_bounds__(256) void rsn_composite_kernel(int n_rays, const in
           t0s += w * x; t1s += w * y; t2s += w * z;
         }
         if (io.pred_normals) {
-          n0 += w * io.pred_normals[o3 + 0]; n1 += w * io.pred_normals[o3 + 1]; n2 += w * io.pred_normals[o3 + 2];
+          const float p0 = io.pred_normals[o3 + 0], p1 = io.pred_normals[o3 + 1], p2 = io.pred_normals[o3 + 2];
+          n0 += w * p0; n1 += w * p1; n2 += w * p2;
+          if (io.pn_loss_ray) {
+            const float e0 = io.normals[o3 + 0] - p0, e1 = io.normals[o3 + 1] - p1, e2 = io.normals[o3 + 2] - p2;
+            pl += w * (e0 * e0 + e1 * e1 + e2 * e2);
+          }
+        }
+        if (io.ori_loss_ray) {
+          const float nd = fmaxf(io.n_dot_d[sbase + i], 0.0f);
+          ol += w * (nd * nd);
         }
         if (io.roughness) rs += w * io.roughness[sbase + i];
       }
@@ -266,7 +276,11 @@ __global__ __launch_bounds__(256) void rsn_composite_kernel(int n_rays, const in
     if (io.tint) { t0s = wave_sum(t0s); t1s = wave_sum(t1s); t2s = wave_sum(t2s); }
     if (io.pred_normals) { n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2); }
     if (io.roughness) rs = wave_sum(rs);
+    if (io.pn_loss_ray) pl = wave_sum(pl);
+    if (io.ori_loss_ray) ol = wave_sum(ol);
     if (lane == 0) {
+      if (io.pn_loss_ray) io.pn_loss_ray[ray] = pl;
+      if (io.ori_loss_ray) io.ori_loss_ray[ray] = ol;
       const float rem = 1.0f - acc;
       float bg0 = 0.0f, bg1 = 0.0f, bg2 = 0.0f;
       if (background == 1) { bg0 = bg1 = bg2 = 1.0f; }
@@ -313,6 +327,8 @@ extern "C" int rsn_composite(int32_t n_rays, const int32_t* n_dev, int32_t n_sam
   RSN_REQUIRE((!io->diff_out || io->diff) && (!io->tint_out || io->tint) && (!io->normals_out || io->pred_normals) &&
                   (!io->roughness_out || io->roughness),
               RSN_ERR_INVALID_ARGUMENT, "a surface-attribute output is requested without its per-sample input");
+  RSN_REQUIRE((!io->pn_loss_ray || (io->normals && io->pred_normals)) && (!io->ori_loss_ray || io->n_dot_d),
+              RSN_ERR_INVALID_ARGUMENT, "a per-ray loss output is requested without its per-sample inputs");
   int blocks = (n_rays + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(rsn_composite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_rays, n_dev, n_samples,

@@ -166,6 +166,121 @@ extern "C" int rsn_loss_scale_grads(int32_t n_rays, int32_t s_coarse, int32_t s_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// get_loss_dict on per-ray quantities (training step): the per-sample normal terms arrive reduced per ray from the
+// compositing epilogue (rsn_composite_io.pn_loss_ray / ori_loss_ray), so one small launch over R rays yields the eight
+// terms and the gradients of the four colour terms; the chain rule is a second launch over R rays.
+// ---------------------------------------------------------------------------------------------------
+struct LossRaysArgs {
+  int R;
+  const float* image;
+  const float* rgb[4];
+  const float* pn_ray[2];
+  const float* ori_ray[2];
+  float coef[8];
+  float* losses;
+  float* g_rgb[4];
+};
+
+__global__ __launch_bounds__(256) void rsn_loss_rays_kernel(const LossRaysArgs a) {
+  __shared__ float sh[4];
+  float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int stride = gridDim.x * blockDim.x;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n3 = a.R * 3;
+  const float inv = 1.0f / (float)n3;
+  for (int e = tid; e < n3; e += stride) {
+    const float img = a.image[e];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dlt = a.rgb[k][e] - img;
+      part[k] += dlt * dlt;
+      if (a.g_rgb[k]) a.g_rgb[k][e] = a.coef[k] * 2.0f * dlt * inv;
+    }
+  }
+  for (int r = tid; r < a.R; r += stride) {
+#pragma unroll
+    for (int lv = 0; lv < 2; ++lv) {
+      part[4 + lv] += a.pn_ray[lv][r];
+      part[6 + lv] += a.ori_ray[lv][r];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = block_sum_256(part[k], sh);
+    if (k < 4) v *= inv;
+    if (threadIdx.x == 0) atomicAdd(&a.losses[k], v);
+  }
+}
+
+extern "C" int rsn_loss_rays_forward(int32_t n_rays, const float* image, const float* const* rgb4,
+                                     const float* const* pn_loss_ray2, const float* const* ori_loss_ray2,
+                                     const float* coef8, float* losses8, float* const* g_rgb4, void* stream) {
+  RSN_REQUIRE(n_rays >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
+  RSN_REQUIRE(image && rgb4 && pn_loss_ray2 && ori_loss_ray2 && coef8 && losses8 && g_rgb4, RSN_ERR_INVALID_ARGUMENT,
+              "a pointer is NULL");
+  LossRaysArgs a;
+  a.R = n_rays; a.image = image; a.losses = losses8;
+  for (int k = 0; k < 4; ++k) { a.rgb[k] = rgb4[k]; a.g_rgb[k] = g_rgb4[k]; RSN_REQUIRE(rgb4[k], RSN_ERR_INVALID_ARGUMENT, "rgb[%d] NULL", k); }
+  for (int k = 0; k < 2; ++k) {
+    a.pn_ray[k] = pn_loss_ray2[k]; a.ori_ray[k] = ori_loss_ray2[k];
+    RSN_REQUIRE(a.pn_ray[k] && a.ori_ray[k], RSN_ERR_INVALID_ARGUMENT, "level %d per-ray loss NULL", k);
+  }
+  for (int k = 0; k < 8; ++k) a.coef[k] = coef8[k];
+  hipStream_t st = (hipStream_t)stream;
+  RSN_HIP(hipMemsetAsync(losses8, 0, 8 * sizeof(float), st));
+  int blocks = (n_rays * 3 + 255) / 256;
+  if (blocks > 64) blocks = 64;  // 8 atomics per block: few blocks, the data is a few hundred KB
+  hipLaunchKernelGGL(rsn_loss_rays_kernel, dim3(blocks), dim3(256), 0, st, a);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+struct LossRaysBwdArgs {
+  int R;
+  const float* up;
+  float coef[8];
+  float* g_rgb[4];
+  float* g_pn_ray[2];
+  float* g_ori_ray[2];
+};
+
+__global__ __launch_bounds__(256) void rsn_loss_rays_bwd_kernel(const LossRaysBwdArgs a) {
+  const int stride = gridDim.x * blockDim.x;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  float up[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) up[k] = a.up[k];
+  for (int e = tid; e < a.R * 3; e += stride) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (a.g_rgb[k]) a.g_rgb[k][e] *= up[k];
+  }
+  for (int r = tid; r < a.R; r += stride) {
+#pragma unroll
+    for (int lv = 0; lv < 2; ++lv) {
+      if (a.g_pn_ray[lv]) a.g_pn_ray[lv][r] = a.coef[4 + lv] * up[4 + lv];
+      if (a.g_ori_ray[lv]) a.g_ori_ray[lv][r] = a.coef[6 + lv] * up[6 + lv];
+    }
+  }
+}
+
+extern "C" int rsn_loss_rays_backward(int32_t n_rays, const float* upstream8, const float* coef8, float* const* g_rgb4,
+                                      float* const* g_pn_ray2, float* const* g_ori_ray2, void* stream) {
+  RSN_REQUIRE(n_rays >= 1, RSN_ERR_INVALID_ARGUMENT, "n_rays=%d", n_rays);
+  RSN_REQUIRE(upstream8 && coef8 && g_rgb4 && g_pn_ray2 && g_ori_ray2, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  LossRaysBwdArgs a;
+  a.R = n_rays; a.up = upstream8;
+  for (int k = 0; k < 8; ++k) a.coef[k] = coef8[k];
+  for (int k = 0; k < 4; ++k) a.g_rgb[k] = g_rgb4[k];
+  for (int k = 0; k < 2; ++k) { a.g_pn_ray[k] = g_pn_ray2[k]; a.g_ori_ray[k] = g_ori_ray2[k]; }
+  int blocks = (n_rays * 3 + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(rsn_loss_rays_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  RSN_HIP(hipGetLastError());
+  return RSN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // RAdam, multi-tensor (torch.optim.RAdam: betas, eps, no weight decay, decoupled = false)
 // ---------------------------------------------------------------------------------------------------
 #define RADAM_MAX_TENSORS 48

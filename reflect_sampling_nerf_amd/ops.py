@@ -94,8 +94,10 @@ def sample_pdf(n_rays: int, n_dev: Optional[Tensor], s_in: int, s_out: int, spac
 
 def composite(n_rays: int, n_dev: Optional[Tensor], n_samples: int, background: int, flags: int, sigma: Tensor,
               euclid_bins: Tensor, color: Tensor, bg_rgb: Optional[Tensor] = None, level: Optional[Dict] = None,
-              surface: bool = False, want_depth: bool = True) -> Dict[str, Tensor]:
-    """-> weights [R,S], rgb [R,3], accumulation [R], depth [R] (+ diff/tint/normals/roughness if surface)."""
+              surface: bool = False, want_depth: bool = True, ray_losses: bool = False) -> Dict[str, Tensor]:
+    """-> weights [R,S], rgb [R,3], accumulation [R], depth [R] (+ diff/tint/normals/roughness if surface;
+    + pn_loss_ray / ori_loss_ray [R] if ray_losses: the per-sample normal losses of get_loss_dict (model.py:403-407)
+    reduced per ray where the weights are in registers; needs level["normals"], ["pred_normals"], ["n_dot_d"])."""
     lib = _abi.load_library()
     dev = sigma.device
     out = {
@@ -119,6 +121,12 @@ def composite(n_rays: int, n_dev: Optional[Tensor], n_samples: int, background: 
         io.pred_normals, io.roughness = ptr(level["pred_normals"]), ptr(level["roughness"])
         io.diff_out, io.tint_out = ptr(out["diff"]), ptr(out["tint"])
         io.normals_out, io.roughness_out = ptr(out["normals"]), ptr(out["roughness"])
+    if ray_losses:
+        assert level is not None
+        out["pn_loss_ray"] = torch.empty(n_rays, device=dev, dtype=torch.float32)
+        out["ori_loss_ray"] = torch.empty(n_rays, device=dev, dtype=torch.float32)
+        io.pred_normals, io.normals, io.n_dot_d = ptr(level["pred_normals"]), ptr(level["normals"]), ptr(level["n_dot_d"])
+        io.pn_loss_ray, io.ori_loss_ray = ptr(out["pn_loss_ray"]), ptr(out["ori_loss_ray"])
     check(lib.rsn_composite(n_rays, ptr(n_dev), n_samples, background, flags, io, _stream()))
     return out
 

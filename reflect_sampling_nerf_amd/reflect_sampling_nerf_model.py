@@ -110,7 +110,7 @@ class ReflectSamplingNeRFModel(Model):
         """Training mode: one autograd node (train_graph.GetOutputsTrain) over the HIP forward/backward kernels.
         `jitter` optionally injects the samplers' uniform draws and `bins` whole sampler outputs
         ({"fine_spacing", "fine_euclid", ...}); tests share them with the oracle / the reference's logged values."""
-        from .train_graph import DIFF_KEYS, GetOutputsTrain
+        from .train_graph import DIFF_KEYS, FUSED_KEYS, GetOutputsTrain
 
         R = ray_bundle.origins.shape[0]
         o = ops._f32c(ray_bundle.origins.reshape(R, 3))
@@ -125,6 +125,8 @@ class ReflectSamplingNeRFModel(Model):
         for k, v in aux.items():
             outputs[k] = v.detach() if v.dtype.is_floating_point else v
         outputs.lazy = aux.lazy
+        # not keys of the reference's dict: the normal losses of get_loss_dict, reduced per ray by the compositing kernel
+        outputs.fused = dict(zip(FUSED_KEYS, outs[len(DIFF_KEYS):]))
         return outputs
 
     @property
@@ -207,11 +209,14 @@ class ReflectSamplingNeRFModel(Model):
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
         """model.py:346-430: four MSE terms against the (white-blended) image, two predicted-normal and two
         orientation terms, scaled by config.loss_coefficients.  One fused HIP pass (train_ops.FusedLoss)."""
-        from .train_ops import fused_loss_dict
+        from .train_ops import fused_loss_dict, fused_ray_loss_dict
 
         image = batch["image"].to(self.device)
         if image.shape[-1] == 4:  # RGBRenderer.blend_background with the white background colour
             image = image[..., :3] * image[..., 3:] + (1.0 - image[..., 3:])
+        fused = getattr(outputs, "fused", None)
+        if fused is not None:  # outputs of this model's own training graph: the per-sample terms are already per-ray sums
+            return fused_ray_loss_dict(outputs, fused, image, self.config.loss_coefficients)
         return fused_loss_dict(outputs, image, self.config.loss_coefficients)
 
     # ------------------------------------------------------------------ eval image (model.py:432-482; "next" row §8(f).4)

@@ -217,8 +217,10 @@ def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], ne
     n, S = eb.shape[0], eb.shape[1] - 1
     gout, gst = _alloc_gout(field, n * S, o.device, need_input)
     gi = FieldGradsIn()
-    for k in ("sigma", "color", "pred_normals", "n_dot_d", "roughness"):
+    for k in ("sigma", "color", "pred_normals", "n_dot_d", "roughness", "ray_pn_loss", "ray_ori_loss"):
         setattr(gi, k, ptr(gin.get(k)))
+    if gin.get("ray_pn_loss") is not None or gin.get("ray_ori_loss") is not None:
+        gi.weights = ptr(gin["weights"])
     fo = ops.field_outputs_struct(level)
     fs = _saved_struct(level["saved"])
     desc = field.field_desc()
@@ -247,6 +249,7 @@ class LazyOutputs(dict):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.lazy: Dict[str, tuple] = {}
+        self.fused: Optional[Dict[str, Tensor]] = None  # FUSED_KEYS tensors for get_loss_dict (set by the model)
 
     def _materialise(self, key):
         count, per_ray = self.lazy.pop(key)
@@ -281,6 +284,9 @@ _LazyAux = LazyOutputs
 # ------------------------------------------------------------------------------------------------ the autograd node
 DIFF_KEYS = ("mid_rgb_coarse", "mid_rgb_fine", "mid_reflect_coarse", "mid_reflect_fine", "pred_normals_coarse",
              "pred_normals_fine", "n_dot_d_coarse", "n_dot_d_fine", "roughness")
+# differentiable per-ray reductions of the normal losses, handed to get_loss_dict beside the reference's keys
+# (LazyOutputs.fused): sum_s w |n - n_pred|^2 and sum_s w max(0, n.d)^2 of the coarse and the fine level
+FUSED_KEYS = ("pn_loss_ray_coarse", "pn_loss_ray_fine", "ori_loss_ray_coarse", "ori_loss_ray_fine")
 
 
 class GetOutputsTrain(torch.autograd.Function):
@@ -339,12 +345,12 @@ class GetOutputsTrain(torch.autograd.Function):
         sb_c, eb_c = level_bins("coarse", R, Sc, lambda: ops.sample_spaced(R, None, Sc, uni.spacing, uni.tan, nears, fars,
                                                                            jit("coarse", R, Sc)))
         lc = fld.evaluate_frustums_train(o, d, pa, eb_c, want_normals=True)
-        cc = ops.composite(R, None, Sc, 1, CLIP, lc["sigma"], eb_c, lc["color"])
+        cc = ops.composite(R, None, Sc, 1, CLIP, lc["sigma"], eb_c, lc["color"], level=lc, ray_losses=True)
         sb_f, eb_f = level_bins("fine", R, Sf, lambda: ops.sample_pdf(
             R, None, Sc, Sf, uni.spacing, uni.tan, model.sampler_pdf.histogram_padding, nears, fars, cc["weights"], sb_c,
             jit("fine", R, Sf)))
         lf = fld.evaluate_frustums_train(o, d, pa, eb_f, want_normals=True)
-        cf = ops.composite(R, None, Sf, 1, CLIP, lf["sigma"], eb_f, lf["color"], level=lf, surface=True)
+        cf = ops.composite(R, None, Sf, 1, CLIP, lf["sigma"], eb_f, lf["color"], level=lf, surface=True, ray_losses=True)
         rs = ops.reflect_setup(o, d, cf["accumulation"], cf["depth"], cf["normals"], cf["roughness"], float(model.far))
         # C.-F. the reflect branch runs on the M <= R rays behind the mask.  Like the eval path (model.get_outputs) every
         # launch is sized for R rays and takes the count from device memory (rs["n_masked"]).  The host never reads M: the
@@ -417,11 +423,13 @@ class GetOutputsTrain(torch.autograd.Function):
         ctx.n_params = len(params)
         model._train_aux = aux
         outs = (cc["rgb"], cf["rgb"], rs["reflect_coarse"], rs["reflect_fine"], lc["pred_normals"], lf["pred_normals"],
-                lc["n_dot_d"].unsqueeze(-1), lf["n_dot_d"].unsqueeze(-1), cf["roughness"].unsqueeze(-1))
+                lc["n_dot_d"].unsqueeze(-1), lf["n_dot_d"].unsqueeze(-1), cf["roughness"].unsqueeze(-1),
+                cc["pn_loss_ray"], cf["pn_loss_ray"], cc["ori_loss_ray"], cf["ori_loss_ray"])
         return outs
 
     @staticmethod
-    def backward(ctx, g_rgb_c, g_rgb_f, g_refl_c, g_refl_f, g_pn_c, g_pn_f, g_ndd_c, g_ndd_f, g_rough):
+    def backward(ctx, g_rgb_c, g_rgb_f, g_refl_c, g_refl_f, g_pn_c, g_pn_f, g_ndd_c, g_ndd_f, g_rough,
+                 g_pnr_c=None, g_pnr_f=None, g_orr_c=None, g_orr_f=None):
         st, model = ctx.st, ctx.model
         fld = model.field
         lib = _abi.load_library()
@@ -481,7 +489,9 @@ class GetOutputsTrain(torch.autograd.Function):
                                  rough_samples=lf["roughness"], g_acc=g_acc)
         gin = {"sigma": cb["g_sigma"], "color": cb["g_color"], "roughness": cb["g_rough"],
                "pred_normals": ops._f32c(g_pn_f) if g_pn_f is not None else None,
-               "n_dot_d": ops._f32c(g_ndd_f.reshape(R, Sf)) if g_ndd_f is not None else None}
+               "n_dot_d": ops._f32c(g_ndd_f.reshape(R, Sf)) if g_ndd_f is not None else None,
+               "ray_pn_loss": ops._f32c(g_pnr_f) if g_pnr_f is not None else None,
+               "ray_ori_loss": ops._f32c(g_orr_f) if g_orr_f is not None else None, "weights": cf["weights"]}
         gout = _field_backward(fld, st["rays"], st["eb_f"], lf, gin, need_input=False)
         pending.append((lf["saved"], gout, True))
         # coarse primary level
@@ -489,7 +499,9 @@ class GetOutputsTrain(torch.autograd.Function):
         cb = _composite_backward(R, Sc, 1, CLIP, 0, lc, st["eb_c"], cc["weights"], g_rgb_c)
         gin = {"sigma": cb["g_sigma"], "color": cb["g_color"],
                "pred_normals": ops._f32c(g_pn_c) if g_pn_c is not None else None,
-               "n_dot_d": ops._f32c(g_ndd_c.reshape(R, Sc)) if g_ndd_c is not None else None}
+               "n_dot_d": ops._f32c(g_ndd_c.reshape(R, Sc)) if g_ndd_c is not None else None,
+               "ray_pn_loss": ops._f32c(g_pnr_c) if g_pnr_c is not None else None,
+               "ray_ori_loss": ops._f32c(g_orr_c) if g_orr_c is not None else None, "weights": cc["weights"]}
         gout = _field_backward(fld, st["rays"], st["eb_c"], lc, gin, need_input=False)
         pending.append((lc["saved"], gout, True))
         _weight_grads(fld, pending, acc)

@@ -1,7 +1,9 @@
 """Loss and optimiser step of the training iteration on the HIP path.
 
-FusedLoss   -- get_loss_dict (reference model.py:346-430): rsn_loss_forward_backward computes the 8 terms and their
-               gradients w.r.t. the model outputs in one pass; autograd only scales them by the upstream gradient.
+FusedLoss   -- get_loss_dict (reference model.py:346-430) on ANY outputs dict: rsn_loss_forward_backward computes the 8
+               terms and their gradients w.r.t. the model outputs in one pass over the samples.
+FusedRayLoss-- the same for outputs of this package's training graph: the per-sample normal terms were already reduced
+               per ray in the compositing epilogue, the loss is two launches over R rays.
 FusedRAdam  -- torch.optim.RAdam semantics (reference config.py:50-53) as one multi-tensor launch (rsn_radam_step),
                with the reference's exponential learning-rate decay (lr 1e-3 -> 1e-4 over 50 000 steps).
 """
@@ -89,6 +91,58 @@ def fused_loss_dict(outputs: Dict[str, Tensor], image: Tensor, coefficients: Dic
                              outputs["pred_normals_coarse"], outputs["pred_normals_fine"], outputs["n_dot_d_coarse"],
                              outputs["n_dot_d_fine"])
     return dict(zip(LOSS_TERMS, scaled.unbind(0)))  # one backward node (a stack) instead of eight select_backwards
+
+
+class FusedRayLoss(torch.autograd.Function):
+    """(image, coef[8], rgb x4 [R,3], pn_loss_ray x2 [R], ori_loss_ray x2 [R]) -> scaled losses [8].
+
+    The training graph reduces the two per-sample normal terms of get_loss_dict (model.py:403-407) per ray inside the
+    compositing kernel, where the weights are in registers (train_graph.FUSED_KEYS); what is left of the loss is work on
+    R rays: one launch forward (rsn_loss_rays_forward), one backward.  The per-sample gradients d/d pred_normals,
+    d/d n_dot_d are formed inside the field's backward kernel from the per-ray upstream gradients returned here."""
+
+    @staticmethod
+    def forward(ctx, image, coef, rgb_c, rgb_f, refl_c, refl_f, pnr_c, pnr_f, orr_c, orr_f):
+        lib = _abi.load_library()
+        f = ops._f32c
+        image = f(image)
+        rgb = [f(rgb_c), f(rgb_f), f(refl_c), f(refl_f)]
+        R = rgb[0].shape[0]
+        pnr, orr = [f(pnr_c), f(pnr_f)], [f(orr_c), f(orr_f)]
+        dev = image.device
+        losses = torch.empty(8, device=dev)
+        g_rgb = [torch.empty_like(t) for t in rgb]
+        coef_arr = (C.c_float * 8)(*[float(c) for c in coef])
+        check(lib.rsn_loss_rays_forward(R, ptr(image), _ptr_array(rgb), _ptr_array(pnr), _ptr_array(orr), coef_arr,
+                                        ptr(losses), _ptr_array(g_rgb), ops._stream()))
+        ctx.g_rgb, ctx.R, ctx.coef_arr = g_rgb, R, coef_arr
+        key = (tuple(float(c) for c in coef), dev)
+        if FusedLoss._coef_cache[0] != key:  # the coefficients change twice per run (warm-up): no per-step upload
+            FusedLoss._coef_cache = (key, torch.tensor([float(c) for c in coef], device=dev))
+        return losses * FusedLoss._coef_cache[1]
+
+    @staticmethod
+    def backward(ctx, g8):
+        lib = _abi.load_library()
+        if ctx.g_rgb is None:
+            raise RuntimeError("FusedRayLoss: the gradient buffers are scaled in place; backward can run once per forward")
+        g_rgb, R = ctx.g_rgb, ctx.R
+        ctx.g_rgb = None
+        dev = g_rgb[0].device
+        g_pn = [torch.empty(R, device=dev), torch.empty(R, device=dev)]
+        g_or = [torch.empty(R, device=dev), torch.empty(R, device=dev)]
+        check(lib.rsn_loss_rays_backward(R, ptr(ops._f32c(g8)), ctx.coef_arr, _ptr_array(g_rgb), _ptr_array(g_pn),
+                                         _ptr_array(g_or), ops._stream()))
+        return (None, None, *g_rgb, *g_pn, *g_or)
+
+
+def fused_ray_loss_dict(outputs: Dict[str, Tensor], fused: Dict[str, Tensor], image: Tensor,
+                        coefficients: Dict[str, float]) -> Dict[str, Tensor]:
+    coef = [float(coefficients.get(k, 1.0)) for k in LOSS_TERMS]
+    scaled = FusedRayLoss.apply(image, coef, outputs["mid_rgb_coarse"], outputs["mid_rgb_fine"],
+                                outputs["mid_reflect_coarse"], outputs["mid_reflect_fine"], fused["pn_loss_ray_coarse"],
+                                fused["pn_loss_ray_fine"], fused["ori_loss_ray_coarse"], fused["ori_loss_ray_fine"])
+    return dict(zip(LOSS_TERMS, scaled.unbind(0)))
 
 
 def exponential_decay_lr(step: int, lr_init: float = 1e-3, lr_final: float = 1e-4, max_steps: int = 50000) -> float:

@@ -1186,6 +1186,42 @@ def test_train_step_without_reflected_rays(dev):
         assert max_abs(out[k].detach().cpu(), ref[k].detach()) <= TOL, k
 
 
+def test_loss_fused_into_compositing_equals_per_sample_loss(dev):
+    """get_loss_dict on the training graph's own outputs takes the per-ray reductions the compositing kernel made
+    (sum_s w |n - n_pred|^2, sum_s w max(0, n.d)^2: reference model.py:403-407) and forms d/d pred_normals, d/d n_dot_d
+    inside the field's backward kernel; on a plain dict of the same tensors it takes the per-sample path
+    (rsn_loss_forward_backward).  Same eight terms, same parameter gradients; and the per-ray sums equal torch's."""
+    model, rb, batch = _train_setup(dev, 200, (24, 40, 16, 16), layers=8, width=128)
+    g = torch.Generator().manual_seed(3)
+    jit = {k: torch.rand(200, s + 1, generator=g).to(dev) for k, s in (("coarse", 24), ("fine", 40))}
+
+    def run(fused):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(11)  # the reflect levels' draws
+        out = model._get_outputs_train(rb, jitter=dict(jit))
+        assert out.fused is not None
+        for lvl in ("coarse", "fine"):
+            w, n, pn = out[f"weights_{lvl}"][..., 0], out[f"normals_{lvl}"], out[f"pred_normals_{lvl}"].detach()
+            ndd = out[f"n_dot_d_{lvl}"][..., 0].detach()
+            assert max_abs((w * ((n - pn) ** 2).sum(-1)).sum(-1), out.fused[f"pn_loss_ray_{lvl}"].detach()) <= 1e-5
+            assert max_abs((w * ndd.clamp(min=0) ** 2).sum(-1), out.fused[f"ori_loss_ray_{lvl}"].detach()) <= 1e-5
+        losses = model.get_loss_dict(out if fused else dict(out), batch)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        return ({k: float(v.detach()) for k, v in losses.items()},
+                {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None})
+
+    l_f, g_f = run(True)
+    l_s, g_s = run(False)
+    assert sorted(l_f) == sorted(l_s)
+    for k in l_s:
+        assert abs(l_f[k] - l_s[k]) <= 2e-6 * max(abs(l_s[k]), 1e-3), k
+    assert sorted(g_f) == sorted(g_s)
+    for n in g_s:
+        scale = float(g_s[n].abs().max()) + 1e-30
+        assert float((g_f[n] - g_s[n]).abs().max()) <= 1e-5 * scale, n
+
+
 def test_device_counted_step_equals_host_counted_step(dev, monkeypatch):
     """Production path (no draws injected: every reflect launch and the weight-gradient segments take M from device
     memory) against the test path (draws injected: M read on the host, reflect draws gathered per reflected ray), with
