@@ -10,6 +10,7 @@ import os
 from ._build import LIB_PATH
 
 RSN_ABI_VERSION = 13
+RSN_ABI_DIAG_FLAG = 0x10000  # rsn_abi_version() of a -DRSN_DIAG_BUILD library (csrc/rsn_common.h)
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
 RSN_SPACING_UNIFORM = 0
@@ -186,8 +187,13 @@ def load_library(path: str = LIB_PATH):
         fn.restype = res
         fn.argtypes = args
     ver = lib.rsn_abi_version()
+    diag, ver = bool(ver & RSN_ABI_DIAG_FLAG), ver & ~RSN_ABI_DIAG_FLAG
     if ver != RSN_ABI_VERSION:
         raise RsnError(f"ABI version mismatch: library {ver}, binding {RSN_ABI_VERSION}")
+    if diag and os.path.abspath(path) == os.path.abspath(LIB_PATH):
+        # -DRSN_DIAG_BUILD libraries (timing ablations with wrong results, phase counters) are tools-only: they are
+        # loaded by explicit path (tools/_variant.py, RSN_LIBRARY), never from the product location
+        raise RsnError(f"{path} is a diagnostic build (RSN_DIAG_BUILD): rebuild it with reflect_sampling_nerf_amd/_build.py")
     _lib = lib
     return lib
 

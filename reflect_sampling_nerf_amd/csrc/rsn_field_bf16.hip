@@ -411,7 +411,8 @@ __device__ __forceinline__ void ring_issue(Ring& r) {
 // group boundary: the group about to be consumed (and the one after it) are in LDS for every wave; the previous
 // group's slot is refilled.  vmcnt counts in issue order, so "all but the youngest PPW*(LEAD-2)" covers every DMA of
 // the two oldest groups in flight.
-// (RSN_RING_NO_*: timing diagnostics of tools/variant_bench.py -- wrong results by construction, never in librsn_hip.so)
+// (RSN_RING_NO_*: timing diagnostics of tools/variant_bench.py -- wrong results by construction; they compile only under
+// -DRSN_DIAG_BUILD, rsn_common.h, and such a library is refused as librsn_hip.so)
 template <int NW>
 __device__ __forceinline__ void ring_sync(Ring& r) {
 #ifdef RSN_RING_NO_BARRIER

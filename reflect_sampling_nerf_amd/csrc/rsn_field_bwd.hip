@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
-#ifdef RSN_BWD_NO_DYSTORE  // timing diagnostic (tools/train_diag.sh): wrong results
+#ifdef RSN_BWD_NO_DYSTORE  // timing diagnostic (RSN_DIAG_BUILD only, tools/train_diag.sh): wrong results
       store_masked_bits<NB>(acc, X, mb, h, nullptr);
 #else
       store_masked_bits<NB>(acc, X, mb, h, valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);

@@ -54,7 +54,11 @@ bool rsn_env_flag(const char* name) {
   last_val = v != nullptr && v[0] != '\0' && v[0] != '0';
   return last_val;
 }
+#ifdef RSN_DIAG_BUILD
+extern "C" int rsn_abi_version(void) { return RSN_ABI_VERSION | RSN_ABI_DIAG_FLAG; }  // never the product library
+#else
 extern "C" int rsn_abi_version(void) { return RSN_ABI_VERSION; }
+#endif
 
 int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   RSN_REQUIRE(d != nullptr, RSN_ERR_INVALID_ARGUMENT, "desc is NULL");

@@ -148,3 +148,26 @@ def test_bench_flop_accounting_matches_survey():
     assert m["backward"] == 3 * 128 + 128 * 256 + (256 + 11) * 256 + 7 * 256 * 256
     assert m["backward_input"] == m["backward"] + 2 * 99 * 256
     assert bench.algorithmic_macs(4, 128)["forward"] == 100736
+
+
+def test_diagnostic_macros_cannot_enter_the_product_library(tmp_path):
+    """Timing ablations (RSN_RING_NO_*, RSN_R16_*, RSN_BWD_NO_DYSTORE: wrong results by construction) compile only under
+    -DRSN_DIAG_BUILD, which the product flags never carry, and a diagnostic library reports RSN_ABI_DIAG_FLAG in
+    rsn_abi_version() (the loader refuses it at the product path)."""
+    import shutil
+    import subprocess
+
+    from reflect_sampling_nerf_amd import _build
+
+    assert not any("RSN_DIAG_BUILD" in f or f.startswith("-DRSN_R") for f in _build.FLAGS)
+    lib = _abi.load_library()
+    assert lib.rsn_abi_version() & _abi.RSN_ABI_DIAG_FLAG == 0
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "probe.hip"
+    src.write_text('#include "rsn_common.h"\nint main() { return 0; }\n')
+    base = [hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-I", os.path.join(REPO, "include"), "-I",
+            _build.CSRC, str(src)]
+    assert subprocess.run(base, capture_output=True).returncode == 0
+    bad = subprocess.run(base + ["-DRSN_R16_NO_MFMA"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "RSN_DIAG_BUILD" in bad.stderr
+    assert subprocess.run(base + ["-DRSN_R16_NO_MFMA", "-DRSN_DIAG_BUILD"], capture_output=True).returncode == 0

@@ -11,7 +11,7 @@ sys.path.insert(0, REPO)
 def build_variant(defines):
     from reflect_sampling_nerf_amd import _build
 
-    flags = ["-D" + d for d in defines]
+    flags = ["-DRSN_DIAG_BUILD"] + ["-D" + d for d in defines]  # marks the library as never-the-product (rsn_common.h)
     tag = hashlib.sha256(" ".join(flags).encode()).hexdigest()[:10]
     out = os.path.join(REPO, "build", "variants")
     os.makedirs(out, exist_ok=True)
