@@ -99,8 +99,11 @@ typedef struct rsn_field_outputs {
   float* raw_roughness;/* [N]    roughness head before its activation field.py:150-155 (caller-chosen act) */
 } rsn_field_outputs;
 
-/* Activations the training-mode forward keeps for the backward pass (all row-major fp32, N = n_rays*n_samples
- * rows; W = width, L = num_layers).  Written by rsn_field_forward_frustum_train. */
+/* Activations the training-mode forward keeps for the backward pass (row-major, N = n_rays*n_samples rows; W = width,
+ * L = num_layers).  Written by rsn_field_forward_frustum_train.  fp32 -- except in the reduced-precision training mode
+ * (rsn_field_desc.mma_mode == RSN_MMA_BF16, whose GEMMs round these values to bf16 anyway): there the three WIDE buffers
+ * act, bott and hid hold bf16 (same shapes, 2 bytes per element; half the step's HBM stream), and so do the wide layer
+ * gradients dy, d_bott, da_mid of rsn_field_grads_out; rsn_weight_grad_multi_dev reads them as such (operand_bf16). */
 typedef struct rsn_field_saved {
   float* enc;     /* [N,104]  encoded inputs (input of trunk layer 0), kernel slot order                   */
   float* act;     /* [L,N,W]  post-ReLU output of trunk layer l (act[L-1] = embedding)                       */
@@ -193,10 +196,10 @@ typedef struct rsn_field_grads_in {
  * dW = dY^T X (plain library GEMMs on the host) and by rsn_colsum (bias gradients). */
 typedef struct rsn_field_grads_out {
   float* dz_rgb;    /* [N,4]   field_output_mid pre-sigmoid (3 live columns)                          */
-  float* da_mid;    /* [N,128] mlp_mid pre-activation                                                  */
-  float* d_bott;    /* [N,W]   bottleneck output                                                       */
+  float* da_mid;    /* [N,128] mlp_mid pre-activation                      (bf16 under RSN_MMA_BF16)   */
+  float* d_bott;    /* [N,W]   bottleneck output                           (bf16 under RSN_MMA_BF16)   */
   float* dz_heads;  /* [N,16]  columns: 0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint      */
-  float* dy;        /* [L,N,W] pre-activation of trunk layer l                                         */
+  float* dy;        /* [L,N,W] pre-activation of trunk layer l             (bf16 under RSN_MMA_BF16)   */
   float* d_input;   /* [N]     d loss / d pixel_area (frustum) or d sqradius (inf); need_input_grad only */
 } rsn_field_grads_out;
 
@@ -364,11 +367,14 @@ int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_points, cons
  * n_dev[s] is not NULL (HOST array of device pointers to int32 counts; per_count = rows per counted unit, i.e. samples
  * per ray), n_points_max[s] rows otherwise.  The reflect branch of a training step runs on the M rays behind the mask
  * (reference model.py:229,259-290); M is produced on the device by rsn_reflect_setup and never read by the host, so the
- * step has no device-to-host synchronisation.  The grid is sized for the upper bounds. */
+ * step has no device-to-host synchronisation.  The grid is sized for the upper bounds.
+ * operand_bf16 (RSN_MMA_BF16 only): bit 0 = the x rows, bit 1 = the dy rows ARE bf16 in memory (the reduced-precision
+ * training mode keeps its wide buffers as bf16, see rsn_field_saved / rsn_field_grads_out); leading dimensions count
+ * elements.  bf16 dy rows need n_out > 32; a shape the vector-load layout does not cover is an error, not a fallback. */
 int rsn_weight_grad_multi_dev(int32_t n_segments, const int64_t* n_points_max, const int32_t* const* n_dev,
                               const int32_t* per_count, const float* const* dy, int32_t ld_dy, int32_t n_out,
                               const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map, float* dw,
-                              int32_t ld_dw, float* db, int32_t mma_mode, void* stream);
+                              int32_t ld_dw, float* db, int32_t mma_mode, int32_t operand_bf16, void* stream);
 
 /* get_loss_dict on per-ray quantities only (training step: the per-sample normal terms arrive reduced per ray from
  * rsn_composite): losses8[k] = the UNSCALED terms (0-3 MSE means of rgb4[k] against image; 4,5 = sum_r pn_loss_ray2[lv][r];

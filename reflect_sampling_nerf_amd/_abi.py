@@ -125,7 +125,7 @@ _SIGNATURES = {
                                              C.c_int32, C.c_void_p]),
     "rsn_weight_grad_multi_dev": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
-                                            C.c_int32, _fp, C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_void_p]),
+                                            C.c_int32, _fp, C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_void_p]),
     "rsn_loss_forward_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp),
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_float), _fp,
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.c_void_p]),

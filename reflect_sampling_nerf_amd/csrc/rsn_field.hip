@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
   constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;  // >= 14 (encoding, K=16 steps) and >= 16 (mid hidden)
   constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
   constexpr int W = NB * 32;
+  constexpr bool SBF = TRAIN && MODE == 3;  // reduced-precision training: activations / bottleneck / mid hidden saved as bf16
   __shared__ float4 smem[4 * WAVE_F4];
 
   const int lane = threadIdx.x & 63;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       for (int l = 1; l < a.num_layers; ++l) {
         pre_mode<MODE, NB>(wpre, pk + a.L.w_x[l], ln);
         // ReLU between layers; the accumulators restart from layer l's bias
-        store_act_init<NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (l - 1) * a.act_stride + pc * W : nullptr,
+        store_act_init<NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (l - 1) * a.act_stride + pc * W) : nullptr,
                                  h, pk + a.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
         RSN_T(3);
         gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, ln);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       }
       // out_activation = ReLU
       pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, ln);
-      store_act<NB, NB, true>(acc, X, (TRAIN && a.saved.act && valid) ? a.saved.act + (a.num_layers - 1) * a.act_stride + pc * W : nullptr, h,
+      store_act<NB, NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (a.num_layers - 1) * a.act_stride + pc * W) : nullptr, h,
                               (TRAIN && a.saved.relu_bits && valid) ? bits_at(a.num_layers - 1) : nullptr);
       RSN_T(3);
     }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         *reinterpret_cast<float4*>(a.saved.heads + pc * 8) = make_float4(r1, r2, r3, r4);
       }
       // bottleneck output (no activation) becomes the x-part of mlp_mid's input
-      store_act<NB + 1, NB, false>(acc, X, (TRAIN && a.saved.bott && valid) ? a.saved.bott + pc * W : nullptr, h);
+      store_act<NB + 1, NB, false, SBF>(acc, X, (TRAIN && a.saved.bott && valid) ? row_ptr<SBF>(a.saved.bott, pc * W) : nullptr, h);
     }
 
     // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       gemm_mode_run<MODE, 4>(accm, wmx, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, ln);
       RSN_T(8);
       pre_mode<MODE, 1>(wrgb, pk + a.L.w_rgb, ln);
-      store_act<4, 4, true>(accm, X, (TRAIN && a.saved.hid && valid) ? a.saved.hid + pc * 128 : nullptr, h,
+      store_act<4, 4, true, SBF>(accm, X, (TRAIN && a.saved.hid && valid) ? row_ptr<SBF>(a.saved.hid, pc * 128) : nullptr, h,
                             (TRAIN && a.saved.relu_bits && valid) ? bits_at(a.num_layers) : nullptr);
       RSN_T(3);
     }

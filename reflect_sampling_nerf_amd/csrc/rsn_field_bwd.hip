@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
   constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;
   constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
   constexpr int W = NB * 32;
+  constexpr bool SBF = MODE == 3;  // reduced-precision training: wide layer gradients (dy, d_bott, da_mid) stored as bf16
   __shared__ float4 smem[4 * WAVE_F4];
 
   const int lane = threadIdx.x & 63;
@@ -172,14 +173,14 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
       f32x16 acc[4];
       zero_acc<4>(acc);
       gemm_mode<MODE, 4>(acc, pk + a.L.wT_rgb, pk + a.L.hT_rgb, X, 4, ln);
-      store_masked_bits<4>(acc, X, mb, h, (valid && a.gout.da_mid) ? a.gout.da_mid + pc * 128 : nullptr);
+      store_masked_bits<4, SBF>(acc, X, mb, h, (valid && a.gout.da_mid) ? row_ptr<SBF>(a.gout.da_mid, pc * 128) : nullptr);
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_mid_x, pk + a.L.hT_mid_x, X, 16, ln);
-      store_act<NB, NB, false>(acc, X, (valid && a.gout.d_bott) ? a.gout.d_bott + pc * W : nullptr, h);
+      store_act<NB, NB, false, SBF>(acc, X, (valid && a.gout.d_bott) ? row_ptr<SBF>(a.gout.d_bott, pc * W) : nullptr, h);
     }
     // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
     {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_bh, pk + a.L.hT_bh, X, NB * 4 + 4, ln);
-      store_masked_bits<NB>(acc, X, mb, h, valid ? a.gout.dy + (long long)l * a.act_stride + pc * W : nullptr);
+      store_masked_bits<NB, SBF>(acc, X, mb, h, valid ? row_ptr<SBF>(a.gout.dy, (long long)l * a.act_stride + pc * W) : nullptr);
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
     f32x16 eacc[4];
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
 #ifdef RSN_BWD_NO_DYSTORE  // timing diagnostic (RSN_DIAG_BUILD only, tools/train_diag.sh): wrong results
-      store_masked_bits<NB>(acc, X, mb, h, nullptr);
+      store_masked_bits<NB, SBF>(acc, X, mb, h, nullptr);
 #else
-      store_masked_bits<NB>(acc, X, mb, h, valid ? a.gout.dy + (long long)(l - 1) * a.act_stride + pc * W : nullptr);
+      store_masked_bits<NB, SBF>(acc, X, mb, h, valid ? row_ptr<SBF>(a.gout.dy, (long long)(l - 1) * a.act_stride + pc * W) : nullptr);
 #endif
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------

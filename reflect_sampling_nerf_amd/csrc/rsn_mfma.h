@@ -341,6 +341,25 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
 }
 
+// Rows kept for the backward pass / the weight gradients.  fp32 rows in the exact and the split-bf16 modes; in the
+// reduced-precision training mode (RSN_MMA_BF16: the GEMMs round these values to bf16 anyway) the wide buffers
+// (activations, bottleneck, mid hidden; layer gradients) are stored AS bf16 -- half the step's HBM stream.  `save`
+// stays a float* in the signatures; SBF reinterprets it as a row of bf16 (element offsets, not bytes).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <bool SBF>
+__device__ __forceinline__ float* row_ptr(float* base, long long elem) {
+  return SBF ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(base) + elem) : base + elem;
+}
+template <bool SBF>
+__device__ __forceinline__ void put4(float* save, int off, const float4 v) {
+  if (SBF) {
+    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(save) + off) = o;
+  } else {
+    *reinterpret_cast<float4*>(save + off) = v;
+  }
+}
+
 // ReLU sign bits of one lane: bit nb*16 + r = (accumulator register r of block nb, the layer's pre-activation) > 0,
 // packed into NBO/2 words (rsn_field_saved.relu_bits).  The dX sweeps mask by these bits instead of re-reading the
 // saved fp32 activations (1 KiB per point and layer -> 32 B; 124 fewer live registers in the sweeps).
@@ -396,7 +415,7 @@ __device__ __forceinline__ ReluBits<NBO> load_relu_bits(const unsigned* __restri
 
 // dX-sweep epilogue on mask bits: X[it][lane] = bit ? acc : 0 (v_bfe_i32 gives 0 / -1, one v_and applies it);
 // optionally also stored to row `save` (backward pass: the layer's pre-activation gradient for the weight gradients)
-template <int NBO>
+template <int NBO, bool SBF = false>
 __device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], float4* xl, const ReluBits<NBO>& m, int h,
                                                   float* save = nullptr) {
 #pragma unroll
@@ -411,14 +430,14 @@ __device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], floa
       v.z = __uint_as_float(__float_as_uint(acc[nb][4 * q + 2]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 2, 1));
       v.w = __uint_as_float(__float_as_uint(acc[nb][4 * q + 3]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 3, 1));
       xl[(nb * 4 + q) * 64] = v;
-      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+      if (save) put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
     }
 }
 
 // X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3])   (bias already inside acc, see init_acc).
 // save (training): the same float4 also goes to row `save` of a row-major [N, 32*NBS] activation buffer
 // (this lane's point; the four q of one nb complete one 128-B line per row).
-template <int NBO, int NBS, bool RELU>
+template <int NBO, int NBS, bool RELU, bool SBF = false>
 __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, float* save = nullptr, int h = 0,
                                           unsigned* bits = nullptr) {
   unsigned bw[NBS / 2 > 0 ? NBS / 2 : 1];
@@ -438,7 +457,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
         v.w = relu_f(v.w);
       }
       xl[(nb * 4 + q) * 64] = v;
-      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+      if (save) put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
     }
   }
   if (RELU && bits) {
@@ -455,7 +474,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
 
 // store_act of one layer fused with init_acc of the next (same NBO): block by block the accumulators are read out and
 // immediately re-loaded with the next layer's bias, so the bias round trip hides under the rest of the epilogue.
-template <int NBO, bool RELU>
+template <int NBO, bool RELU, bool SBF = false>
 __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, float* save, int h,
                                                const float* __restrict__ bias, unsigned* bits = nullptr) {
   unsigned bw[NBO / 2 > 0 ? NBO / 2 : 1];
@@ -475,7 +494,7 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, f
         v.w = relu_f(v.w);
       }
       xl[(nb * 4 + q) * 64] = v;
-      if (save) *reinterpret_cast<float4*>(save + (nb * 4 + q) * 8 + 4 * h) = v;
+      if (save) put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
       const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
       acc[nb][4 * q + 0] = bv.x;
       acc[nb][4 * q + 1] = bv.y;

@@ -48,8 +48,13 @@ struct WGradArgs {
 //   BF = 3 (RSN_MMA_BF16X6): both operands split exactly into bf16 triples as they are packed, the 6 leading products
 //          (dropped terms <= 2^-24 relative): fp32-equivalent at 2.7x the fp32 MFMA rate;
 //   BF = 1 (RSN_MMA_BF16, the opt-in reduced-precision training mode): operands rounded to bf16, one product.
-template <int NKB, bool XV, bool DV, int BF = 0>
+//   XB / DB (BF = 1 only): the X / dY rows ARE bf16 in memory (reduced-precision training saves its wide buffers as
+//          bf16: rsn_field_saved, rsn_field_grads_out): half the bytes of this HBM-bound variant, no conversion; a lane's
+//          8 points x {2 rows | NKB columns} arrive as packed words and are regrouped per row / column by v_perm_b32.
+template <int NKB, bool XV, bool DV, int BF = 0, bool XB = false, bool DB = false>
 __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
+  static_assert(!(XB || DB) || (BF == 1 && XV), "bf16 rows: the plain-bf16 variant with vector loads of X only");
+  static_assert(!DB || DV, "bf16 dY rows come as (row 2i, row 2i+1) pairs");
   constexpr int NP = BF ? 8 : WG_PAIRS;  // points per lane and stage
   __shared__ float tr[4][2][NKB * 32];
   const int lane = threadIdx.x & 63;
@@ -111,7 +116,12 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     }
   }
 
-  float fa[2][NP][2], fb[2][NP][NKB];  // [buffer][point of this lane][block]
+  // Stage buffers.  fp32 rows: 80 registers per stage, two fit beside the 256 accumulators (one stage = 512 MFMA cycles of
+  // cover for the next one's loads).  bf16 rows are 40 registers per stage: FOUR buffers, three stages (1536 MFMA cycles)
+  // in flight -- the plain-bf16 reduction is bound by load latency, not by bytes (profiles/r03_wgrad_rows.txt).
+  constexpr int NBUF = (DB && (XB || NKB <= 4)) ? 4 : 2;  // (fp32 X rows of <= 128 columns are <= 40 registers per stage too)
+  float fa[NBUF][DB ? 1 : NP][2], fb[NBUF][XB ? 1 : NP][NKB];  // [buffer][point of this lane][block]
+  unsigned ua[NBUF][DB ? NP : 1], ub[NBUF][XB ? NP : 1][NKB / 2];  // bf16 rows: packed pairs (rows 2i, 2i+1 | columns 2w, 2w+1)
   auto roff = [&](int p) { return BF ? 8 * h + p : 2 * p + h; };  // row of the stage this lane's p-th point is
   const float* __restrict__ dyp = nullptr;
   const float* __restrict__ xp = nullptr;
@@ -119,7 +129,10 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   auto load_row = [&](int buf, int p, long long m, bool in) {
     const float* __restrict__ dr = dyp + m * a.ld_dy;
     const float* __restrict__ xr = xp + m * a.ld_x;
-    if (DV) {
+    if constexpr (DB) {
+      const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const __bf16*>(dyp) + m * a.ld_dy + cdy[0]);
+      ua[buf][p] = in ? v : 0u;
+    } else if constexpr (DV) {
       const float2 v = *reinterpret_cast<const float2*>(dr + cdy[0]);
       fa[buf][p][0] = in ? v.x : 0.0f;
       fa[buf][p][1] = in ? v.y : 0.0f;
@@ -130,7 +143,20 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
         fa[buf][p][t] = in ? v : 0.0f;
       }
     }
-    if (XV && NKB >= 4) {
+    if constexpr (XB) {
+      const __bf16* __restrict__ xb = reinterpret_cast<const __bf16*>(xp) + m * a.ld_x + cx[0];
+      if constexpr (NKB == 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(xb);
+        ub[buf][p][0] = in ? v.x : 0u; ub[buf][p][1] = in ? v.y : 0u;
+        ub[buf][p][2] = in ? v.z : 0u; ub[buf][p][3] = in ? v.w : 0u;
+      } else if constexpr (NKB == 4) {
+        const uint2 v = *reinterpret_cast<const uint2*>(xb);
+        ub[buf][p][0] = in ? v.x : 0u; ub[buf][p][1] = in ? v.y : 0u;
+      } else {
+        const unsigned v = *reinterpret_cast<const unsigned*>(xb);
+        ub[buf][p][0] = in ? v : 0u;
+      }
+    } else if constexpr (XV && NKB >= 4) {
 #pragma unroll
       for (int q = 0; q < NKB / 4; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(xr + cx[0] + 4 * q);
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
         fb[buf][p][4 * q + 2] = in ? v.z : 0.0f;
         fb[buf][p][4 * q + 3] = in ? v.w : 0.0f;
       }
-    } else if (XV) {
+    } else if constexpr (XV) {
       const float2 v = *reinterpret_cast<const float2*>(xr + cx[0]);
       fb[buf][p][0] = in ? v.x : 0.0f;
       fb[buf][p][1] = in ? v.y : 0.0f;
@@ -152,7 +178,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     }
   };
   auto mma_stage = [&](int buf) {
-    if (BF == 3) {
+    if constexpr (BF == 3) {
       bf16x8 a1[2], a2[2], a3[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -193,21 +219,48 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
           acc[t][kb] = c;
         }
       }
-      return;
-    }
-    if (BF) {
+    } else if constexpr (BF != 0) {
       bf16x8 av[2], bv[NKB];
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      if constexpr (DB) {  // packed (row 2i, row 2i+1) pairs of 8 points -> one bf16x8 per row: v_perm_b32 picks the halves
+        u32x4 lo, hi;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          bsum[t] += fa[buf][p][t];
-          av[t][p] = (__bf16)fa[buf][p][t];
+        for (int j = 0; j < 4; ++j) {
+          const unsigned w0 = ua[buf][2 * j], w1 = ua[buf][2 * j + 1];
+          lo[j] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+          hi[j] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+          bsum[0] += __uint_as_float(w0 << 16) + __uint_as_float(w1 << 16);
+          bsum[1] += __uint_as_float(w0 & 0xffff0000u) + __uint_as_float(w1 & 0xffff0000u);
         }
+        av[0] = __builtin_bit_cast(bf16x8, lo);
+        av[1] = __builtin_bit_cast(bf16x8, hi);
+      } else {
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bv[kb][p] = (__bf16)fb[buf][p][kb];
+          for (int p = 0; p < NP; ++p) {
+            bsum[t] += fa[buf][p][t];
+            av[t][p] = (__bf16)fa[buf][p][t];
+          }
+      }
+      if constexpr (XB) {
+#pragma unroll
+        for (int w = 0; w < NKB / 2; ++w) {
+          u32x4 lo, hi;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = __builtin_amdgcn_perm(ub[buf][2 * j + 1][w], ub[buf][2 * j][w], 0x05040100u);
+            hi[j] = __builtin_amdgcn_perm(ub[buf][2 * j + 1][w], ub[buf][2 * j][w], 0x07060302u);
+          }
+          bv[2 * w] = __builtin_bit_cast(bf16x8, lo);
+          bv[2 * w + 1] = __builtin_bit_cast(bf16x8, hi);
+        }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) bv[kb][p] = (__bf16)fb[buf][p][kb];
+      }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (t == 1 && !t1_live) continue;
@@ -215,17 +268,17 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
         for (int kb = 0; kb < NKB; ++kb)
           acc[t][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t], bv[kb], acc[t][kb], 0, 0, 0);
       }
-      return;
-    }
+    } else {
 #pragma unroll
-    for (int p = 0; p < WG_PAIRS; ++p) {
+      for (int p = 0; p < WG_PAIRS; ++p) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (t == 1 && !t1_live) continue;
-        bsum[t] += fa[buf][p][t];
+        for (int t = 0; t < 2; ++t) {
+          if (t == 1 && !t1_live) continue;
+          bsum[t] += fa[buf][p][t];
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-          acc[t][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][p][t], fb[buf][p][kb], acc[t][kb], 0, 0, 0);
+          for (int kb = 0; kb < NKB; ++kb)
+            acc[t][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][p][t], fb[buf][p][kb], acc[t][kb], 0, 0, 0);
+        }
       }
     }
   };
@@ -255,31 +308,70 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     dyp = a.dy[s];
     xp = a.x[s];
     const long long gs = G * step;
+    // stage t of this slot starts at row (first + t G) step; the prefetch index is clamped, never branched on (straight-line
+    // loop bodies let the scheduler slot the loads between the MFMAs)
+    auto load_stage = [&](int buf, long long t) {
+      const long long tc = t < cnt ? t : cnt - 1;
+      const long long m0 = (first + tc * G) * step;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) load_row(buf, p, m0 + roff(p), true);
+    };
     if (cnt > 0) {
       any = true;
+      if constexpr (NBUF == 4) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) load_row(0, p, first * step + roff(p), true);
+        for (int b = 0; b < NBUF - 1; ++b) load_stage(b, b);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) load_row(0, p, first * step + roff(p), true);
+      }
     }
     long long j = 0;
+    if constexpr (NBUF == 4) {
 #pragma unroll 1
-    for (; j + 1 < cnt; j += 2) {
-      const long long m0 = (first + j * G) * step;
-      // the next stage's loads (and their address arithmetic) are slotted between this stage's MFMAs: issued as a
-      // block between two MFMA bursts they left the matrix pipe idle for ~10 % of the loop.  Straight-line body
-      // (the prefetch index is clamped, not branched on) so that the scheduler can interleave.
+      for (; j + 3 < cnt; j += 4) {
+        load_stage(3, j + 3);
+        mma_stage(0);
+        interleave_stage();
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(0, j + 4);
+        mma_stage(1);
+        interleave_stage();
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(1, j + 5);
+        mma_stage(2);
+        interleave_stage();
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(2, j + 6);
+        mma_stage(3);
+        interleave_stage();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (j < cnt) mma_stage(0);      // the last 0..3 stages are in buffers 0..2 already
+      if (j + 1 < cnt) mma_stage(1);
+      if (j + 2 < cnt) mma_stage(2);
+    } else {
+      const long long gs = G * step;
+#pragma unroll 1
+      for (; j + 1 < cnt; j += 2) {
+        const long long m0 = (first + j * G) * step;
+        // the next stage's loads (and their address arithmetic) are slotted between this stage's MFMAs: issued as a
+        // block between two MFMA bursts they left the matrix pipe idle for ~10 % of the loop.  Straight-line body
+        // (the prefetch index is clamped, not branched on) so that the scheduler can interleave.
 #pragma unroll
-      for (int p = 0; p < NP; ++p) load_row(1, p, m0 + gs + roff(p), true);
-      mma_stage(0);
-      interleave_stage();
-      __builtin_amdgcn_sched_barrier(0);
-      const long long m2 = (j + 2 < cnt) ? m0 + 2 * gs : m0 + gs;
+        for (int p = 0; p < NP; ++p) load_row(1, p, m0 + gs + roff(p), true);
+        mma_stage(0);
+        interleave_stage();
+        __builtin_amdgcn_sched_barrier(0);
+        const long long m2 = (j + 2 < cnt) ? m0 + 2 * gs : m0 + gs;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) load_row(0, p, m2 + roff(p), true);
-      mma_stage(1);
-      interleave_stage();
-      __builtin_amdgcn_sched_barrier(0);
+        for (int p = 0; p < NP; ++p) load_row(0, p, m2 + roff(p), true);
+        mma_stage(1);
+        interleave_stage();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (j < cnt) mma_stage(0);
     }
-    if (j < cnt) mma_stage(0);
     if (rem > 0 && (vprefix + n_full) % G == g) {  // the segment's tail stage: points beyond n_s contribute zeros
       any = true;
 #pragma unroll
@@ -329,7 +421,8 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   }
 }
 
-static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0) {
+static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0, int operand_bf16 = 0) {
+  const bool xb = (operand_bf16 & 1) != 0, db = (operand_bf16 & 2) != 0;  // rows that ARE bf16 in memory
   bool bf16 = mode == RSN_MMA_BF16 || mode == RSN_MMA_BF16X6;
   const long long total = a.seg_begin[a.n_seg];
   if (total == 0) return RSN_OK;
@@ -338,13 +431,19 @@ static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0) {
   // waves share the stages; T(G) = stages / (G * nsub) * t_stage + G * t_flush is smallest at G = sqrt(...)
   const int nkb = a.k_in > 128 ? 8 : (a.k_in > 64 ? 4 : 2), nkb_ = nkb;
   // vector-load variants need whole NKB-column groups and aligned rows; anything else takes the scalar-load path
-  bool xv = a.k_in % nkb == 0 && a.ld_x % (nkb >= 4 ? 4 : 2) == 0;
+  bool xv = a.k_in % nkb == 0 && a.ld_x % (xb ? nkb : (nkb >= 4 ? 4 : 2)) == 0;
   bool dv = a.n_out > 32 && a.ld_dy % 2 == 0 && a.ld_dy >= a.n_out + (a.n_out & 1);
   for (int s = 0; s < a.n_seg; ++s) {
-    xv = xv && ((uintptr_t)a.x[s] % 16 == 0);
-    dv = dv && ((uintptr_t)a.dy[s] % 8 == 0);
+    xv = xv && ((uintptr_t)a.x[s] % (xb ? 2 * nkb : 16) == 0);
+    dv = dv && ((uintptr_t)a.dy[s] % (db ? 4 : 8) == 0);
   }
-  bf16 = bf16 && xv && dv;  // the bf16 variant exists for the vector-load layout only
+  if (xb || db) {  // no other kernel can read bf16 rows: the layout must fit, loudly
+    RSN_REQUIRE(mode == RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "bf16 operand rows need mma_mode RSN_MMA_BF16");
+    RSN_REQUIRE(xv && (!db || dv), RSN_ERR_UNSUPPORTED,
+                "bf16 operand rows: k_in=%d ld_x=%d n_out=%d ld_dy=%d / alignment do not fit the vector-load layout",
+                a.k_in, a.ld_x, a.n_out, a.ld_dy);
+  }
+  bf16 = bf16 && xv && (dv || (xb && !db));  // the bf16 variants exist for the vector-load layout only
   const int P = a.n_out <= 64 ? 1 : (a.n_out <= 128 ? 2 : 4);
   const int nsub = 4 / P;
   long long stages = 0;
@@ -364,6 +463,14 @@ static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0) {
   do {                                                                                                         \
     if (xv && dv && bf16 && mode == RSN_MMA_BF16X6)                                                            \
       hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);  \
+    else if (bf16 && xb && db)                                                                                 \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+    else if (bf16 && db)                                                                                       \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+    else if (bf16 && xb && !dv)                                                                                \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, false, 1, true, false>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+    else if (bf16 && xb)                                                                                       \
+      { RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "bf16 X rows with fp32 dY rows wider than 32 outputs"); }      \
     else if (xv && dv && bf16)                                                                                 \
       hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);  \
     else if (xv && dv)                                                                                         \
@@ -387,7 +494,8 @@ static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0) {
 static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                   int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
                                   const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode,
-                                  const int32_t* const* n_dev = nullptr, const int32_t* per_count = nullptr);
+                                  const int32_t* const* n_dev = nullptr, const int32_t* per_count = nullptr,
+                                  int operand_bf16 = 0);
 
 extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                      int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
@@ -398,7 +506,7 @@ extern "C" int rsn_weight_grad_multi(int32_t n_segments, const int64_t* n_points
 static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, const float* const* dy, int32_t ld_dy,
                                   int32_t n_out, const float* const* x, int32_t ld_x, int32_t k_in,
                                   const int32_t* col_map, float* dw, int32_t ld_dw, float* db, void* stream, int mode,
-                                  const int32_t* const* n_dev, const int32_t* per_count) {
+                                  const int32_t* const* n_dev, const int32_t* per_count, int operand_bf16) {
   RSN_REQUIRE(n_segments >= 0 && n_segments <= WG_MAX_SEG, RSN_ERR_INVALID_ARGUMENT, "n_segments=%d (at most %d)",
               n_segments, WG_MAX_SEG);
   RSN_REQUIRE(n_out >= 1 && n_out <= 256 && k_in >= 1 && k_in <= 256, RSN_ERR_INVALID_ARGUMENT,
@@ -424,7 +532,7 @@ static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, c
   a.n_seg = ns;
   a.ld_dy = ld_dy; a.ld_x = ld_x; a.n_out = n_out; a.k_in = k_in;
   a.ld_dw = ld_dw; a.col_map = col_map; a.dw = dw; a.db = db;
-  return wgrad_launch(a, stream, mode);
+  return wgrad_launch(a, stream, mode, operand_bf16);
 }
 
 extern "C" int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_points, const float* const* dy,
@@ -439,11 +547,13 @@ extern "C" int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_p
 extern "C" int rsn_weight_grad_multi_dev(int32_t n_segments, const int64_t* n_points_max, const int32_t* const* n_dev,
                                          const int32_t* per_count, const float* const* dy, int32_t ld_dy, int32_t n_out,
                                          const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map,
-                                         float* dw, int32_t ld_dw, float* db, int32_t mma_mode, void* stream) {
+                                         float* dw, int32_t ld_dw, float* db, int32_t mma_mode, int32_t operand_bf16,
+                                         void* stream) {
   RSN_REQUIRE(mma_mode >= RSN_MMA_F32 && mma_mode <= RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "mma_mode %d", mma_mode);
   RSN_REQUIRE(n_segments == 0 || (n_dev && per_count), RSN_ERR_INVALID_ARGUMENT, "n_dev / per_count is NULL");
+  RSN_REQUIRE(operand_bf16 >= 0 && operand_bf16 <= 3, RSN_ERR_INVALID_ARGUMENT, "operand_bf16 %d", operand_bf16);
   return weight_grad_multi_impl(n_segments, n_points_max, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream,
-                                mma_mode, n_dev, per_count);
+                                mma_mode, n_dev, per_count, operand_bf16);
 }
 
 extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x,

@@ -224,8 +224,7 @@ class ReflectSamplingNeRFNerfField(Field):
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         level = {"sigma": f(R, S), "color": f(R, S, 3), "pred_normals": f(R, S, 3), "n_dot_d": f(R, S),
                  "diff": f(R, S, 3), "tint": f(R, S, 3), "roughness": f(R, S), "raw_density": f(R, S)}
-        saved = {"enc": f(N, 104), "act": f(L, N, W), "bott": f(N, W), "sh": f(N, 40), "hid": f(N, 128),
-                 "heads": f(N, 8), "relu_bits": torch.empty(L + 1, N, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
+        saved = self.alloc_saved(N, dev)
         if want_normals:
             saved["normals"] = f(R, S, 3)
         fo = ops.field_outputs_struct(level)
@@ -244,6 +243,22 @@ class ReflectSamplingNeRFNerfField(Field):
         if want_normals:
             level["normals"] = saved["normals"]
         return level
+
+    def wide_dtype(self) -> torch.dtype:
+        """dtype of the WIDE training buffers (saved act / bott / hid, layer gradients dy / d_bott / da_mid): bf16 in the
+        reduced-precision training mode (RSN_MMA_BF16: its GEMMs round these values to bf16 anyway -- half the step's HBM
+        stream and activation memory), fp32 otherwise (include/rsn.h: rsn_field_saved)."""
+        return torch.bfloat16 if int(self.mma_mode) == _abi.RSN_MMA_BF16 else torch.float32
+
+    def alloc_saved(self, N: int, dev) -> Dict[str, Tensor]:
+        """The buffers a training-mode forward over N points fills (rsn_field_saved)."""
+        W, L = self.width, self.mlp_base.num_layers
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        wd = self.wide_dtype()
+        return {"enc": f(N, 104), "act": torch.empty(L, N, W, device=dev, dtype=wd),
+                "bott": torch.empty(N, W, device=dev, dtype=wd), "sh": f(N, 40),
+                "hid": torch.empty(N, 128, device=dev, dtype=wd), "heads": f(N, 8),
+                "relu_bits": torch.empty(L + 1, N, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
 
     def evaluate_inf(self, directions: Tensor, sqradius: Tensor, n_dev: Optional[Tensor] = None) -> Tensor:
         """get_inf_color on M (<= len) rays: directions [R,3], sqradius [R] -> rgb [R,3]."""

@@ -96,9 +96,10 @@ def _saved_struct(saved: Dict[str, Tensor]) -> FieldSaved:
 
 def _alloc_gout(field, N: int, dev, need_input: bool):
     W, L = field.width, field.mlp_base.num_layers
-    g = {"dz_rgb": torch.empty(N, 4, device=dev), "da_mid": torch.empty(N, 128, device=dev),
-         "d_bott": torch.empty(N, W, device=dev), "dz_heads": torch.empty(N, 16, device=dev),
-         "dy": torch.empty(L, N, W, device=dev)}
+    wd = field.wide_dtype()  # bf16 in the reduced-precision training mode (rsn_field_grads_out)
+    g = {"dz_rgb": torch.empty(N, 4, device=dev), "da_mid": torch.empty(N, 128, device=dev, dtype=wd),
+         "d_bott": torch.empty(N, W, device=dev, dtype=wd), "dz_heads": torch.empty(N, 16, device=dev),
+         "dy": torch.empty(L, N, W, device=dev, dtype=wd)}
     if need_input:
         g["d_input"] = torch.empty(N, device=dev)
     st = FieldGradsOut()
@@ -166,13 +167,16 @@ def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Opti
     ndev = (C.c_void_p * ns)(*[None if c is None else c[0].data_ptr() for c in cnt])
     per = (C.c_int32 * ns)(*[1 if c is None else int(c[1]) for c in cnt])
     dwp = C.c_void_p(dw.data_ptr() + 4 * dw_col0)
+    bf = torch.bfloat16  # rows that are bf16 in memory (reduced-precision training): all segments alike
+    assert all((sg[0].dtype == bf) == (segs[0][0].dtype == bf) and (sg[1].dtype == bf) == (segs[0][1].dtype == bf) for sg in segs)
+    operand_bf16 = (1 if segs[0][1].dtype == bf else 0) | (2 if segs[0][0].dtype == bf else 0)
     work = {"point_out_in": sum(sg[0].shape[0] for sg in segs if len(sg) < 3 or sg[2] is None) * n_out * k_in}
     dev_work = [(c[0], c[1] * n_out * k_in) for c in cnt if c is not None]
     if dev_work:
         work["point_out_in_dev"] = dev_work
     ops.timed("weight_grad", work,
               lambda: check(lib.rsn_weight_grad_multi_dev(ns, npts, ndev, per, dys, ld_dy, n_out, xs, ld_x, k_in, ptr(col_map),
-                                                          dwp, dw.stride(0), ptr(db), _WGRAD_MODE, ops._stream())))
+                                                          dwp, dw.stride(0), ptr(db), _WGRAD_MODE, operand_bf16, ops._stream())))
 
 
 def _weight_grads(field, levels, acc: _GradAcc):
@@ -366,8 +370,7 @@ class GetOutputsTrain(torch.autograd.Function):
         near2, far2 = rs["nears2"], rs["fars2"]
         f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
         # get_inf_color in training mode (activations saved)
-        inf_saved = {"enc": f(R, 104), "act": f(L, R, W), "bott": f(R, W), "sh": f(R, 40), "hid": f(R, 128),
-                     "heads": f(R, 8), "relu_bits": torch.empty(L + 1, R, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
+        inf_saved = fld.alloc_saved(R, dev)
         bg = f(R, 3)
         desc = fld.field_desc()
         fs = _saved_struct(inf_saved)

@@ -941,6 +941,41 @@ def test_weight_grad_mma_modes(dev, monkeypatch, n_out, k_in, mode):
     assert float((got - exact_w).abs().max()) <= 2e-2 * float(exact_w.abs().max())  # bf16 rounding of both operands
 
 
+@pytest.mark.parametrize("n_out,k_in,x_bf16,dy_bf16", [(256, 256, True, True), (256, 104, False, True), (128, 40, False, True),
+                                                       (128, 256, True, True), (16, 256, True, False), (3, 128, True, False),
+                                                       (64, 64, True, True), (256, 128, True, True)])
+def test_weight_grad_bf16_rows(dev, monkeypatch, n_out, k_in, x_bf16, dy_bf16):
+    """rsn_weight_grad_multi_dev with operand rows that ARE bf16 in memory (the reduced-precision training mode keeps
+    its wide buffers as bf16: rsn_field_saved / rsn_field_grads_out): every operand combination the training step
+    produces -- wide layers (both bf16), encoded / SH inputs (fp32 X, bf16 dY), heads and RGB head (bf16 X, narrow fp32 dY)
+    -- over several segments, one of them cut by a DEVICE-side count.  Equals the fp64 product of the bf16 values to fp32
+    accumulation accuracy; bias sums are sums of the stored (bf16) rows."""
+    from reflect_sampling_nerf_amd import train_graph
+
+    g = torch.Generator().manual_seed(7 * n_out + k_in)
+    lens = [1000, 37, 5003, 640]
+    count = torch.tensor([9], dtype=torch.int32, device=dev)  # the last segment holds 9 x 64 = 576 of its 640 rows
+    segs = []
+    ref_w, ref_b = torch.zeros(n_out, k_in, dtype=torch.float64), torch.zeros(n_out, dtype=torch.float64)
+    for si, n in enumerate(lens):
+        dy, x = torch.randn(n, n_out, generator=g), torch.randn(n, k_in, generator=g)
+        ld_dy = n_out + (n_out & 1) if n_out > 32 else (16 if n_out > 4 else 4)
+        dyp = torch.zeros(n, ld_dy)
+        dyp[:, :n_out] = dy
+        dyd = dyp.to(dev).bfloat16() if dy_bf16 else dyp.to(dev)
+        xd = x.to(dev).bfloat16() if x_bf16 else x.to(dev)
+        live = 576 if si == 3 else n
+        # (rows that arrive as fp32 are rounded to bf16 by the kernel as it packs them: the mode's arithmetic)
+        ref_w += dyd[:live, :n_out].bfloat16().double().cpu().t() @ xd[:live].bfloat16().double().cpu()
+        ref_b += dyd[:live, :n_out].double().cpu().sum(0)
+        segs.append((dyd, xd, (count, 64)) if si == 3 else (dyd, xd))
+    dw, db = torch.zeros(n_out, k_in, device=dev), torch.zeros(n_out, device=dev)
+    monkeypatch.setattr(train_graph, "_WGRAD_MODE", 3)
+    train_graph._wgrad_multi(segs, n_out, k_in, dw, 0, db)
+    assert float((dw.double().cpu() - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max())
+    assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+
+
 def test_standalone_sh34_encoding_matches_reference_golden(dev):
     """IntegratedSHEncoding called as a module (rsn_sh34_encode) against the output of the reference's own
     IntegratedSHEncoding.forward (tests/golden/units.npz, oracle/make_golden.py) and against the oracle."""
@@ -1392,8 +1427,9 @@ def test_baseline_config2_training_step_properties(dev):
 
 def test_reduced_precision_training_bf16_sweeps(dev):
     """Opt-in reduced-precision training (the reference trains under autocast, config.py:33): with mma mode "bf16" the
-    training forward and the backward sweeps run on plain bf16 MFMA operands (fp32 accumulation, fp32 saved activations,
-    exact-fp32 weight-gradient kernel).  Against the exact-fp32 HIP step on the same rays and jitter: rendered outputs
+    training forward and the backward sweeps run on plain bf16 MFMA operands with fp32 accumulation; the wide saved
+    activations and layer gradients are STORED as bf16 and the weight-gradient kernel reads them as such (fp32
+    accumulation).  Against the exact-fp32 HIP step on the same rays and jitter: rendered outputs
     within the bf16 tolerance, every parameter gradient in direction (cosine >= 0.99) and size (rel-L2 <= 8e-2)."""
     R, samples = 96, (16, 16, 8, 8)
     grads, outs = {}, {}
