@@ -980,25 +980,30 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_ring16_kernel(const Fie
         }
       }
     }
-    // slot u = 8 kk + el of this lane: u < 12 sin(c = u / 4, frequency 4g + u % 4), 12 <= u < 24 the cos, 24..26 raw
+    // slot u = 8 kk + el of this lane: u < 12 sin(c = u / 4, frequency 4g + u % 4), 12 <= u < 24 the cos, 24..26 raw.
+    // The 24 features of a point are collected in registers and leave as three 16-byte stores (round 2 wrote 48 single
+    // bf16 per point: ds_write_b16 at a 16-byte lane stride is a 4-way bank conflict).
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-#pragma unroll 1
+      float feat[24];
+#pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float x = (c == 0) ? mcA[p][0] : (c == 1 ? mcA[p][1] : mcA[p][2]);
-        const float v = (c == 0) ? vcA[p][0] : (c == 1 ? vcA[p][1] : vcA[p][2]);
+        const float x = mcA[p][c], v = vcA[p][c];
         const float sx = 6.283185307179586f * x;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const float f = a.freqs[4 * g + t];
           const float ang = sx * f;
           const float e = has_cov ? __builtin_amdgcn_exp2f((-0.5f * (v * (f * f))) * 1.4426950408889634f) : 1.0f;
-          const float fs = e * sincos_bf16(ang, 0);
-          const float fc = e * sincos_bf16(ang + 1.5707963267948966f, 0);
-          const int u = c * 4 + t, u2 = u + 12;
-          STs[((u >> 3) * 2 + p) * 512 + (u & 7)] = (__bf16)fs;
-          STs[((u2 >> 3) * 2 + p) * 512 + (u2 & 7)] = (__bf16)fc;
+          feat[c * 4 + t] = e * sincos_bf16(ang, 0);
+          feat[12 + c * 4 + t] = e * sincos_bf16(ang + 1.5707963267948966f, 0);
         }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const float v8[8] = {feat[8 * kk], feat[8 * kk + 1], feat[8 * kk + 2], feat[8 * kk + 3],
+                             feat[8 * kk + 4], feat[8 * kk + 5], feat[8 * kk + 6], feat[8 * kk + 7]};
+        ST[(kk * 2 + p) * 64] = pack8(v8);
       }
       const float rw[8] = {g == 0 ? mcA[p][0] : 0.0f, g == 0 ? mcA[p][1] : 0.0f, g == 0 ? mcA[p][2] : 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       ST[(3 * 2 + p) * 64] = pack8(rw);
