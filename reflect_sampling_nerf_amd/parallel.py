@@ -12,7 +12,9 @@ all-reduce + 1/world scale on the side stream -> event -> the compute stream wai
 the caller enqueues that does not touch the gradients overlaps with the collective.
 
   * Which parameters never receive a gradient on any rank (field_output_low: built by field.py:67, never evaluated)
-    is decided ONCE, on the first call, by one extra flag all-reduce; they are dropped from the flat buffer.
+    is decided on the first call by one extra flag all-reduce; they are dropped from the flat buffer.  Should a dropped
+    parameter receive a gradient later (a host-side check of `.grad is not None`, no device read), the decision is taken
+    again, so replicas cannot diverge silently.
   * The per-step "was used" flags of the live parameters travel in the tail of the same flat buffer.  They are kept on
     the device (one cached tensor per distinct None-pattern) and are only read back on a step where THIS rank lacks a
     gradient some other rank may have produced -- which the reflect-sampling model never does (train_graph.py hands
@@ -51,6 +53,7 @@ class FlatGradAllReduce:
         used = t.cpu()
         self.host_syncs += 1
         self.params = [p for p, u in zip(self.all_params, used.tolist()) if u > 0.0]
+        self._dropped = [p for p, u in zip(self.all_params, used.tolist()) if u <= 0.0]
         self.sizes = [p.numel() for p in self.params]
         self.total = sum(self.sizes)
         n = self.total + len(self.params)  # gradients + one "was used" flag per live parameter
@@ -77,6 +80,11 @@ class FlatGradAllReduce:
         if world == 1 and not self.run_single_rank:
             return
         if self.params is None:
+            self._decide_live()
+        elif any(p.grad is not None for p in self._dropped):
+            # a parameter that had no gradient on ANY rank at the first step has one now (host-only check, no device read):
+            # decide again -- every rank must then do so in the same step, which holds when the model's control flow is the
+            # same on all ranks (DDP with find_unused_parameters=True re-discovers unused parameters every step)
             self._decide_live()
         flat = self._flat
         have = tuple(p.grad is not None for p in self.params)

@@ -55,6 +55,15 @@ def _worker(rank, world, port, out):
             ok &= torch.allclose(params[i].grad, torch.full_like(params[i], 1.5 + step))
         ok &= params[3].grad is None
     ok &= reducer.host_syncs == syncs_before
+    # a parameter dropped as "never used" receives a gradient later (on every rank): the reducer notices on the host,
+    # decides again (one more flag all-reduce) and averages it from then on -- replicas cannot diverge silently
+    params[3].grad = torch.full_like(params[3], float(rank + 1))
+    for i in range(3):
+        params[i].grad = torch.full_like(params[i], float(rank))
+    reducer()
+    ok &= len(reducer.params) == 4 and torch.allclose(params[3].grad, torch.full_like(params[3], 1.5))
+    ok &= torch.allclose(params[0].grad, torch.full_like(params[0], 0.5))
+    ok &= reducer.host_syncs == syncs_before + 1
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
