@@ -175,6 +175,29 @@ int rsn_field_forward_frustum_train(const rsn_field_desc* desc, const float* pac
                                     const float* directions, const float* pixel_area, const float* euclid_bins,
                                     const rsn_field_outputs* out, const rsn_field_saved* saved, void* stream);
 
+/* Several training-mode evaluations of the SAME field in ONE launch: the reflect branch of a step evaluates the field on
+ * M reflected rays x S samples (model.py:292-297, 317-323) and on M points for get_inf_color (model.py:290) -- a few hundred
+ * to ~1,250 tiles of 128 points on 256 persistent workgroups each.  Launched one by one every evaluation wastes its last
+ * partial round of tiles and get_inf_color keeps 20 CUs busy for a whole launch; as jobs of one launch their tiles form
+ * one tile space.  kind 0 = rsn_field_forward_frustum_train's arguments, kind 1 = rsn_field_forward_inf_train's. */
+typedef struct rsn_field_job {
+  int32_t kind;              /* 0: conical frustums of rays; 1: get_inf_color */
+  int32_t n_rays;
+  const int32_t* n_dev;      /* optional device-side ray count */
+  int32_t n_samples;         /* kind 0 */
+  const float* origins;      /* kind 0 */
+  const float* directions;
+  const float* pixel_area;   /* kind 0 */
+  const float* euclid_bins;  /* kind 0 */
+  const float* sqradius;     /* kind 1 */
+  float* out_rgb;            /* kind 1: [n_rays,3] */
+  const rsn_field_outputs* out;  /* kind 0 */
+  const rsn_field_saved* saved;
+} rsn_field_job;
+
+int rsn_field_forward_train_jobs(const rsn_field_desc* desc, const float* packed, int32_t n_jobs,
+                                 const rsn_field_job* jobs, void* stream);
+
 /* ---- backward of one field level (training) ----------------------------------------------------
  * Upstream gradients per sample (NULL = zero) ... */
 typedef struct rsn_field_grads_in {
@@ -202,6 +225,31 @@ typedef struct rsn_field_grads_out {
   float* dy;        /* [L,N,W] pre-activation of trunk layer l             (bf16 under RSN_MMA_BF16)   */
   float* d_input;   /* [N]     d loss / d pixel_area (frustum) or d sqradius (inf); need_input_grad only */
 } rsn_field_grads_out;
+
+/* The backward sweeps of several evaluations of the same field in ONE launch (see rsn_field_job): kind 0 =
+ * rsn_field_backward_frustum's arguments, kind 1 = rsn_field_backward_inf's (g_rgb = upstream gradient of its colour).
+ * The sweeps of the two reflect levels and of get_inf_color are independent of each other once both levels' compositing
+ * backward has produced the background gradient. */
+typedef struct rsn_field_bwd_job {
+  int32_t kind;
+  int32_t n_rays;
+  const int32_t* n_dev;
+  int32_t n_samples;         /* kind 0 */
+  int32_t need_input_grad;
+  const float* origins;      /* kind 0 */
+  const float* directions;
+  const float* pixel_area;   /* kind 0 */
+  const float* euclid_bins;  /* kind 0 */
+  const float* sqradius;     /* kind 1 */
+  const float* g_rgb;        /* kind 1: [n_rays,3] */
+  const rsn_field_outputs* fwd;      /* kind 0 */
+  const rsn_field_saved* saved;
+  const rsn_field_grads_in* gin;     /* kind 0 */
+  const rsn_field_grads_out* gout;
+} rsn_field_bwd_job;
+
+int rsn_field_backward_jobs(const rsn_field_desc* desc, const float* packed, int32_t n_jobs,
+                            const rsn_field_bwd_job* jobs, void* stream);
 
 /* rsn_field_backward_frustum: backward of rsn_field_forward_frustum_train.  fwd: the forward's per-sample
  * outputs (raw_density, diff, tint are read).  need_input_grad != 0 additionally carries the gradient through

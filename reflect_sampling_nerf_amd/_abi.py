@@ -57,6 +57,13 @@ class FieldSaved(C.Structure):
     _fields_ = [(n, _fp) for n in ("enc", "act", "bott", "sh", "hid", "heads", "normals", "relu_bits")]
 
 
+class FieldJob(C.Structure):
+    """rsn_field_job: one evaluation of a multi-evaluation training launch (rsn_field_forward_train_jobs)."""
+    _fields_ = [("kind", C.c_int32), ("n_rays", C.c_int32), ("n_dev", C.c_void_p), ("n_samples", C.c_int32),
+                ("origins", _fp), ("directions", _fp), ("pixel_area", _fp), ("euclid_bins", _fp), ("sqradius", _fp),
+                ("out_rgb", _fp), ("out", C.POINTER(FieldOutputs)), ("saved", C.POINTER(FieldSaved))]
+
+
 class FieldGradsIn(C.Structure):
     _fields_ = [(n, _fp) for n in ("sigma", "color", "pred_normals", "n_dot_d", "roughness", "ray_pn_loss", "ray_ori_loss",
                                    "weights")]
@@ -64,6 +71,14 @@ class FieldGradsIn(C.Structure):
 
 class FieldGradsOut(C.Structure):
     _fields_ = [(n, _fp) for n in ("dz_rgb", "da_mid", "d_bott", "dz_heads", "dy", "d_input")]
+
+
+class FieldBwdJob(C.Structure):
+    """rsn_field_bwd_job: one evaluation of a multi-evaluation backward launch (rsn_field_backward_jobs)."""
+    _fields_ = [("kind", C.c_int32), ("n_rays", C.c_int32), ("n_dev", C.c_void_p), ("n_samples", C.c_int32),
+                ("need_input_grad", C.c_int32), ("origins", _fp), ("directions", _fp), ("pixel_area", _fp),
+                ("euclid_bins", _fp), ("sqradius", _fp), ("g_rgb", _fp), ("fwd", C.POINTER(FieldOutputs)),
+                ("saved", C.POINTER(FieldSaved)), ("gin", C.POINTER(FieldGradsIn)), ("gout", C.POINTER(FieldGradsOut))]
 
 
 class CompositeBwdIO(C.Structure):
@@ -123,6 +138,8 @@ _SIGNATURES = {
     "rsn_weight_grad_multi_mode": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                              C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _fp, C.c_void_p, C.c_int32, _fp,
                                              C.c_int32, C.c_void_p]),
+    "rsn_field_forward_train_jobs": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, C.POINTER(FieldJob), C.c_void_p]),
+    "rsn_field_backward_jobs": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, C.POINTER(FieldBwdJob), C.c_void_p]),
     "rsn_weight_grad_multi_dev": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                             C.c_int32, _fp, C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_void_p]),

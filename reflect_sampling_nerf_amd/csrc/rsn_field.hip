@@ -46,7 +46,7 @@ extern "C" int rsn_debug_phase_cycles(unsigned long long* out16, int reset) {
 
 // ------------------------------------------------------------------------------------------------
 template <int NB, bool TRAIN, int MODE>
-__global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
+__global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
   constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;  // >= 14 (encoding, K=16 steps) and >= 16 (mid hidden)
   constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
   constexpr int W = NB * 32;
@@ -59,20 +59,34 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
   float4* AUX = X + XITS * 64;
   float* Xf = reinterpret_cast<float*>(X);
 
-  int n_rays = a.n_rays;
-  if (a.n_dev) {
-    const int nd = *a.n_dev;
-    n_rays = nd < n_rays ? nd : n_rays;
+  const FieldShared& P = J.s;
+  // the launch's tile space: job k owns tiles [tb_k, tb_k+1) of 128 points (its ray count may live on the device)
+  long long np0 = 0, np1 = 0, np2 = 0, tb1 = 0, tb2 = 0, n_tiles = 0;
+#pragma unroll
+  for (int k = 0; k < RSN_MAX_JOBS; ++k) {
+    if (k < J.n_jobs) {
+      int nr = J.j[k].n_rays;
+      if (J.j[k].n_dev) {
+        const int nd = *J.j[k].n_dev;
+        nr = nd < nr ? nd : nr;
+      }
+      const long long np = (long long)nr * J.j[k].S;
+      if (k == 0) np0 = np; else if (k == 1) np1 = np; else np2 = np;
+      n_tiles += (np + 127) / 128;
+    }
+    if (k == 0) tb1 = n_tiles; else if (k == 1) tb2 = n_tiles;
   }
-  const long long n_points = (long long)n_rays * a.S;
-  const long long n_tiles = (n_points + 127) / 128;
-  const float* __restrict__ pk = a.packed;
+  const float* __restrict__ pk = P.packed;
 #ifdef RSN_PHASE_TIMERS
   long long tacc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = clock64();
 #endif
 
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (long long gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
+    const int jk = (gtile >= tb1 ? 1 : 0) + (gtile >= tb2 ? 1 : 0);  // workgroup-uniform
+    const FieldJob& a = J.j[jk];
+    const long long n_points = jk == 0 ? np0 : (jk == 1 ? np1 : np2);
+    const long long tile = gtile - (jk == 0 ? 0 : (jk == 1 ? tb1 : tb2));
     const long long p0 = tile * 128 + wid * 32;
     if (p0 >= n_points) continue;  // wave-uniform; waves never synchronise with each other
     // an opaque copy of the lane id per tile: per-lane weight / output addresses are then not loop-invariant, so hipcc
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     bool has_cov = true, has_dir = true;
     float4 wbh[NB + 1];  // first weight fragment of the bottleneck+heads GEMM
     if (a.mode == RSN_MODE_EMB) {
-      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, ln);
+      pre_mode<MODE, NB + 1>(wbh, pk + P.L.w_bh, ln);
       // granular Field API: heads / mid MLP on a caller-supplied embedding (field.py:139-186)
       has_dir = a.view_dirs != nullptr;
 #pragma unroll
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       const float sx = 6.283185307179586f * x;
 #pragma unroll 2
       for (int jj = 0; jj < 8; ++jj) {
-        const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
+        const float f = h ? P.freqs[8 + jj] : P.freqs[jj];
         const float ang = sx * f;
         const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
         const float fs = e * sin_big(ang);
@@ -186,22 +200,22 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     {
       f32x16 acc[NB];
       float4 wpre[NB];  // first weight fragment of the next GEMM, fetched ahead of the epilogue in front of it
-      pre_mode<MODE, NB>(wpre, pk + a.L.w_enc0, ln);
-      init_acc<NB>(acc, pk + a.L.b[0], h);
+      pre_mode<MODE, NB>(wpre, pk + P.L.w_enc0, ln);
+      init_acc<NB>(acc, pk + P.L.b[0], h);
       RSN_T(1);
-      gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc0, pk + a.L.h_enc0, X, RSN_ENC_ITS, ln);
+      gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_enc0, pk + P.L.h_enc0, X, RSN_ENC_ITS, ln);
       RSN_T(2);
 #pragma unroll 1
-      for (int l = 1; l < a.num_layers; ++l) {
-        pre_mode<MODE, NB>(wpre, pk + a.L.w_x[l], ln);
+      for (int l = 1; l < P.num_layers; ++l) {
+        pre_mode<MODE, NB>(wpre, pk + P.L.w_x[l], ln);
         // ReLU between layers; the accumulators restart from layer l's bias
         store_act_init<NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (l - 1) * a.act_stride + pc * W) : nullptr,
-                                 h, pk + a.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
+                                 h, pk + P.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
         RSN_T(3);
-        gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_x[l], pk + a.L.h_x[l], X, NB * 4, ln);
+        gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_x[l], pk + P.L.h_x[l], X, NB * 4, ln);
         RSN_T(4);
-        if (l == a.skip_layer) {
-          pre_mode<MODE, NB>(wpre, pk + a.L.w_enc_skip, ln);
+        if (l == P.skip_layer) {
+          pre_mode<MODE, NB>(wpre, pk + P.L.w_enc_skip, ln);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             X[it * 64] = make_float4(st0[4 * it], st0[4 * it + 1], st0[4 * it + 2], st0[4 * it + 3]);
@@ -210,14 +224,14 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           }
           X[12 * 64] = st3;
           if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          gemm_mode_run<MODE, NB>(acc, wpre, pk + a.L.w_enc_skip, pk + a.L.h_enc_skip, X, RSN_ENC_ITS, ln);
+          gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_enc_skip, pk + P.L.h_enc_skip, X, RSN_ENC_ITS, ln);
           RSN_T(2);
         }
       }
       // out_activation = ReLU
-      pre_mode<MODE, NB + 1>(wbh, pk + a.L.w_bh, ln);
-      store_act<NB, NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (a.num_layers - 1) * a.act_stride + pc * W) : nullptr, h,
-                              (TRAIN && a.saved.relu_bits && valid) ? bits_at(a.num_layers - 1) : nullptr);
+      pre_mode<MODE, NB + 1>(wbh, pk + P.L.w_bh, ln);
+      store_act<NB, NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (P.num_layers - 1) * a.act_stride + pc * W) : nullptr, h,
+                              (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers - 1) : nullptr);
       RSN_T(3);
     }
     }  // mode != RSN_MODE_EMB
@@ -232,11 +246,11 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     float4 wmid[4];  // first weight fragment of mlp_mid's SH part
     {
       f32x16 acc[NB + 1];
-      init_acc<NB + 1>(acc, pk + a.L.b_bh, h);
+      init_acc<NB + 1>(acc, pk + P.L.b_bh, h);
       RSN_T(1);
-      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + a.L.w_bh, pk + a.L.h_bh, X, NB * 4, ln);
+      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + P.L.w_bh, pk + P.L.h_bh, X, NB * 4, ln);
       RSN_T(5);
-      pre_mode<MODE, 4>(wmid, pk + a.L.w_mid_sh, ln);
+      pre_mode<MODE, 4>(wmid, pk + P.L.w_mid_sh, ln);
       const float r0 = acc[NB][0], r1 = acc[NB][1], r2 = acc[NB][2], r3 = acc[NB][3];
       const float r4 = acc[NB][4], r5 = acc[NB][5], r6 = acc[NB][6];
       // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
           float nx = -(r1 / nrm), ny = -(r2 / nrm), nz = -(r3 / nrm);
           nrm = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
           nx /= nrm; ny /= nrm; nz /= nrm;
-          if (a.out.sigma) a.out.sigma[pc] = softplus_f(r0 + a.density_bias);
+          if (a.out.sigma) a.out.sigma[pc] = softplus_f(r0 + P.density_bias);
           if (a.out.raw_density) a.out.raw_density[pc] = r0;
           if (a.out.pred_normals) {
             a.out.pred_normals[pc * 3 + 0] = nx;
@@ -307,24 +321,24 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     float4 wrgb[1];
     {
       f32x16 accm[4];
-      init_acc<4>(accm, pk + a.L.b_mid, h);
+      init_acc<4>(accm, pk + P.L.b_mid, h);
       RSN_T(1);
       float4 wmx[4];
-      pre_mode<MODE, 4>(wmx, pk + a.L.w_mid_x, ln);
-      gemm_mode_run<MODE, 4>(accm, wmid, pk + a.L.w_mid_sh, pk + a.L.h_mid_sh, AUX, RSN_SH_ITS, ln);
+      pre_mode<MODE, 4>(wmx, pk + P.L.w_mid_x, ln);
+      gemm_mode_run<MODE, 4>(accm, wmid, pk + P.L.w_mid_sh, pk + P.L.h_mid_sh, AUX, RSN_SH_ITS, ln);
       RSN_T(7);
-      gemm_mode_run<MODE, 4>(accm, wmx, pk + a.L.w_mid_x, pk + a.L.h_mid_x, X, NB * 4, ln);
+      gemm_mode_run<MODE, 4>(accm, wmx, pk + P.L.w_mid_x, pk + P.L.h_mid_x, X, NB * 4, ln);
       RSN_T(8);
-      pre_mode<MODE, 1>(wrgb, pk + a.L.w_rgb, ln);
+      pre_mode<MODE, 1>(wrgb, pk + P.L.w_rgb, ln);
       store_act<4, 4, true, SBF>(accm, X, (TRAIN && a.saved.hid && valid) ? row_ptr<SBF>(a.saved.hid, pc * 128) : nullptr, h,
-                            (TRAIN && a.saved.relu_bits && valid) ? bits_at(a.num_layers) : nullptr);
+                            (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers) : nullptr);
       RSN_T(3);
     }
     {
       f32x16 accr[1];
-      init_acc<1>(accr, pk + a.L.b_rgb, h);
+      init_acc<1>(accr, pk + P.L.b_rgb, h);
       RSN_T(1);
-      gemm_mode_run<MODE, 1>(accr, wrgb, pk + a.L.w_rgb, pk + a.L.h_rgb, X, 16, ln);
+      gemm_mode_run<MODE, 1>(accr, wrgb, pk + P.L.w_rgb, pk + P.L.h_rgb, X, 16, ln);
       RSN_T(9);
       if (h == 1 && valid) {
         const float m0 = sigmoid_f(accr[0][0]);
@@ -351,10 +365,10 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
     // through sin(2 pi x f [+ pi/2]) * exp(-var f^2 / 2) is closed per lane (the covariance is a constant here,
     // exactly like the reference, which sets requires_grad on the mean after contraction).
     if (TRAIN && a.saved.normals && a.saved.relu_bits) {
-      const float* __restrict__ wd = pk + a.L.v_density;
+      const float* __restrict__ wd = pk + P.L.v_density;
       {
         // seed: the density-head row masked by the embedding's ReLU (bits of the last trunk layer)
-        const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(a.num_layers - 1));
+        const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(P.num_layers - 1));
 #pragma unroll
         for (int it = 0; it < NB * 4; ++it) {
           const float4 w = *reinterpret_cast<const float4*>(wd + it * 8 + 4 * h);
@@ -371,19 +385,19 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
       zero_acc<4>(eacc);
       RSN_T(13);
 #pragma unroll 1
-      for (int l = a.num_layers - 1; l >= 1; --l) {
-        if (l == a.skip_layer) gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, ln);
+      for (int l = P.num_layers - 1; l >= 1; --l) {
+        if (l == P.skip_layer) gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc_skip, pk + P.L.hT_enc_skip, X, NB * 4, ln);
         const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l - 1));
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[NB];
         zero_acc<NB>(acc);
         RSN_T(13);
-        gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
+        gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln);
         RSN_T(12);
         store_masked_bits<NB>(acc, X, mb, h);
       }
       RSN_T(13);
-      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, ln);
+      gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln);
       RSN_T(12);
       store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
       float nrm[3];
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
         float part = 0.0f;
 #pragma unroll 2
         for (int jj = 0; jj < 8; ++jj) {
-          const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
+          const float f = h ? P.freqs[8 + jj] : P.freqs[jj];
           const float ang = sx * f;
           const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
           const int u = c * 8 + jj;
@@ -427,43 +441,59 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
-  int rc = rsn_compute_layout(d, &a.L);
+// One launch over n evaluations (all training or all eval; the plain-bf16 eval kernels take one).
+static int launch_field_jobs(const rsn_field_desc* d, FieldArgs* js, int n, void* stream) {
+  RSN_REQUIRE(n >= 1 && n <= RSN_MAX_JOBS, RSN_ERR_INVALID_ARGUMENT, "n_jobs=%d (1..%d)", n, RSN_MAX_JOBS);
+  FieldJobs J = {};
+  int rc = rsn_compute_layout(d, &J.s.L);
   if (rc != RSN_OK) return rc;
-  RSN_REQUIRE(a.packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "packed weights pointer is NULL");
-  a.num_layers = d->num_layers;
-  a.skip_layer = d->skip_layer;
-  a.width = d->width;
-  a.density_bias = d->density_bias;
-  for (int i = 0; i < RSN_NUM_FREQS; ++i) a.freqs[i] = d->freqs[i];
-  if (a.n_rays <= 0) return RSN_OK;
-  const long long n_points = (long long)a.n_rays * a.S;
-  const long long n_tiles = (n_points + 127) / 128;
+  RSN_REQUIRE(js[0].packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "packed weights pointer is NULL");
+  J.s.packed = js[0].packed;
+  J.s.num_layers = d->num_layers;
+  J.s.skip_layer = d->skip_layer;
+  J.s.width = d->width;
+  J.s.density_bias = d->density_bias;
+  for (int i = 0; i < RSN_NUM_FREQS; ++i) J.s.freqs[i] = d->freqs[i];
+  const bool train = js[0].saved.act != nullptr || js[0].saved.enc != nullptr || js[0].saved.heads != nullptr;
+  long long n_tiles = 0;
+  for (int k = 0; k < n; ++k) {
+    FieldArgs& a = js[k];
+    if (a.n_rays <= 0) continue;
+    const bool tk = a.saved.act != nullptr || a.saved.enc != nullptr || a.saved.heads != nullptr;
+    RSN_REQUIRE(tk == train, RSN_ERR_INVALID_ARGUMENT, "job %d: training and eval evaluations cannot share a launch", k);
+    const long long n_points = (long long)a.n_rays * a.S;
+    a.act_stride = n_points * (long long)d->width;
+    n_tiles += (n_points + 127) / 128;
+    J.j[J.n_jobs++] = static_cast<const FieldJob&>(a);
+  }
+  if (J.n_jobs == 0) return RSN_OK;
   const int cus = rsn_device_cus();
   // one 4-wave workgroup per CU (one wave per SIMD, LDS slab 148 KiB at W=256): persistent tiles
   const long long grid = n_tiles < (long long)cus ? n_tiles : (long long)cus;
   hipStream_t st = (hipStream_t)stream;
-  const bool train = a.saved.act != nullptr || a.saved.enc != nullptr || a.saved.heads != nullptr;
-  a.act_stride = n_points * (long long)d->width;
   const int mode = d->mma_mode;
   if (!train && mode == RSN_MMA_BF16) {  // plain bf16 operands: its own kernel, two workgroups per CU
+    RSN_REQUIRE(J.n_jobs == 1, RSN_ERR_UNSUPPORTED, "the plain-bf16 eval kernels take one evaluation per launch");
+    FieldArgs one = {};
+    static_cast<FieldShared&>(one) = J.s;
+    static_cast<FieldJob&>(one) = J.j[0];
     const long long g2 = n_tiles < 2LL * cus ? n_tiles : 2LL * cus;
-    return rsn_launch_field_bf16(d->width, g2, st, a);
+    return rsn_launch_field_bf16(d->width, g2, st, one);
   }
 #define RSN_LAUNCH(NBV)                                                                                          \
   do {                                                                                                           \
     if (train && mode == RSN_MMA_BF16X6)                                                                        \
-      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, J);            \
     else if (train && mode == RSN_MMA_BF16)  /* reduced-precision training: plain bf16 operands, fp32 accumulate */ \
-      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, J);            \
     else if (train)  /* BF16X3 is an eval-only opt-in: training falls back to exact fp32 */                      \
-      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);            \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, J);            \
     else if (mode == RSN_MMA_BF16X6)                                                                            \
-      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, J);           \
     else if (mode == RSN_MMA_BF16X3)                                                                            \
-      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, J);           \
     else                                                                                                         \
-      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);           \
+      hipLaunchKernelGGL((rsn_field_kernel<NBV, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, J);           \
   } while (0)
   switch (d->width) {
     case 256: RSN_LAUNCH(8); break;
@@ -474,6 +504,44 @@ static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) {
 #undef RSN_LAUNCH
   RSN_HIP(hipGetLastError());
   return RSN_OK;
+}
+
+static int launch_field(const rsn_field_desc* d, FieldArgs& a, void* stream) { return launch_field_jobs(d, &a, 1, stream); }
+
+// rsn_field_forward_train_jobs: several training-mode evaluations of the SAME field in one launch.
+extern "C" int rsn_field_forward_train_jobs(const rsn_field_desc* desc, const float* packed, int32_t n_jobs,
+                                            const rsn_field_job* jobs, void* stream) {
+  RSN_REQUIRE(desc && jobs, RSN_ERR_INVALID_ARGUMENT, "desc/jobs is NULL");
+  RSN_REQUIRE(n_jobs >= 1 && n_jobs <= RSN_MAX_JOBS, RSN_ERR_INVALID_ARGUMENT, "n_jobs=%d (1..%d)", n_jobs, RSN_MAX_JOBS);
+  FieldArgs js[RSN_MAX_JOBS] = {};
+  for (int k = 0; k < n_jobs; ++k) {
+    const rsn_field_job& q = jobs[k];
+    FieldArgs& a = js[k];
+    RSN_REQUIRE(q.kind == 0 || q.kind == 1, RSN_ERR_INVALID_ARGUMENT, "job %d: kind=%d", k, q.kind);
+    RSN_REQUIRE(q.n_rays >= 0 && q.saved, RSN_ERR_INVALID_ARGUMENT, "job %d: n_rays=%d / saved is NULL", k, q.n_rays);
+    RSN_REQUIRE(q.saved->act && q.saved->enc && q.saved->bott && q.saved->sh && q.saved->hid && q.saved->heads &&
+                    q.saved->relu_bits,
+                RSN_ERR_INVALID_ARGUMENT, "job %d: training needs every saved-activation buffer (normals may be NULL)", k);
+    a.packed = packed;
+    a.n_rays = q.n_rays; a.n_dev = q.n_dev;
+    a.saved = *q.saved;
+    if (q.kind == 0) {
+      RSN_REQUIRE(q.n_samples >= 1 && q.out, RSN_ERR_INVALID_ARGUMENT, "job %d: n_samples=%d / out is NULL", k, q.n_samples);
+      RSN_REQUIRE(q.n_rays == 0 || (q.origins && q.directions && q.pixel_area && q.euclid_bins), RSN_ERR_INVALID_ARGUMENT,
+                  "job %d: a ray input pointer is NULL", k);
+      a.mode = RSN_MODE_FRUSTUM; a.S = q.n_samples;
+      a.origins = q.origins; a.directions = q.directions; a.pixel_area = q.pixel_area; a.bins = q.euclid_bins;
+      a.out = *q.out;
+    } else {
+      RSN_REQUIRE(q.n_rays == 0 || (q.directions && q.sqradius && q.out_rgb), RSN_ERR_INVALID_ARGUMENT,
+                  "job %d: an input pointer is NULL", k);
+      a.mode = RSN_MODE_INF; a.S = 1;
+      a.directions = q.directions; a.sqradius = q.sqradius;
+      a.out.color = q.out_rgb;
+      a.saved.normals = nullptr;
+    }
+  }
+  return launch_field_jobs(desc, js, n_jobs, stream);
 }
 
 extern "C" int rsn_field_forward_frustum(const rsn_field_desc* desc, const float* packed, int32_t n_rays,

@@ -20,12 +20,17 @@
 //   back to pixel_area (need_input_grad).
 #include "rsn_mfma.h"
 
-struct BwdArgs {
+#include "rsn_field_common.h"
+
+struct BwdShared {
   const float* packed;
   RsnPackedLayout L;
   int num_layers, skip_layer;
   float density_bias;
   float freqs[RSN_NUM_FREQS];
+};
+
+struct BwdJob {
   int mode, n_rays, S, need_input_grad;
   const int* n_dev;
   const float* origins;
@@ -38,6 +43,16 @@ struct BwdArgs {
   rsn_field_saved saved;
   rsn_field_grads_out gout;
   long long act_stride;
+};
+
+struct BwdArgs : BwdShared, BwdJob {};
+
+// Several evaluations in one launch (see FieldJobs, rsn_field_common.h): the backward sweeps of the two reflect levels and
+// of get_inf_color are independent of each other once the compositing backward of both levels has run.
+struct BwdJobs {
+  BwdShared s;
+  int n_jobs;
+  BwdJob j[RSN_MAX_JOBS];
 };
 
 // d var_c / d pixel_area for a conical-frustum sample after contraction (the mean does not depend on pixel_area):
@@ -103,7 +118,7 @@ __device__ __forceinline__ void normalize_bwd(const float x[3], const float gy[3
 }
 
 template <int NB, int MODE>
-__global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
   constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;
   constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
   constexpr int W = NB * 32;
@@ -115,17 +130,31 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
   float4* X = smem + wid * WAVE_F4 + lane;  // its XITS.. spill into the SH region (contiguous): NB*4+4 <= XITS+5
   float* Xf = reinterpret_cast<float*>(X);
 
-  int n_rays = a.n_rays;
-  if (a.n_dev) {
-    const int nd = *a.n_dev;
-    n_rays = nd < n_rays ? nd : n_rays;
+  const BwdShared& P = J.s;
+  // the launch's tile space: job k owns tiles [tb_k, tb_k+1) of 128 points (its ray count may live on the device)
+  long long np0 = 0, np1 = 0, np2 = 0, tb1 = 0, tb2 = 0, n_tiles = 0;
+#pragma unroll
+  for (int k = 0; k < RSN_MAX_JOBS; ++k) {
+    if (k < J.n_jobs) {
+      int nr = J.j[k].n_rays;
+      if (J.j[k].n_dev) {
+        const int nd = *J.j[k].n_dev;
+        nr = nd < nr ? nd : nr;
+      }
+      const long long np = (long long)nr * J.j[k].S;
+      if (k == 0) np0 = np; else if (k == 1) np1 = np; else np2 = np;
+      n_tiles += (np + 127) / 128;
+    }
+    if (k == 0) tb1 = n_tiles; else if (k == 1) tb2 = n_tiles;
   }
-  const long long n_points = (long long)n_rays * a.S;
-  const long long n_tiles = (n_points + 127) / 128;
-  const float* __restrict__ pk = a.packed;
+  const float* __restrict__ pk = P.packed;
   const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
-  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (long long gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
+    const int jk = (gtile >= tb1 ? 1 : 0) + (gtile >= tb2 ? 1 : 0);  // workgroup-uniform
+    const BwdJob& a = J.j[jk];
+    const long long n_points = jk == 0 ? np0 : (jk == 1 ? np1 : np2);
+    const long long tile = gtile - (jk == 0 ? 0 : (jk == 1 ? tb1 : tb2));
     const long long p0 = tile * 128 + wid * 32;
     if (p0 >= n_points) continue;
     // opaque per-tile copy of the lane id: keeps hipcc from hoisting (and spilling) per-lane addresses out of the loop
@@ -168,18 +197,18 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     X[0] = (h == 1) ? make_float4(dz_rgb[0], dz_rgb[1], dz_rgb[2], 0.0f) : zero4;
     X[64] = zero4; X[128] = zero4; X[192] = zero4;
     {
-      const ReluBits<4> mb = load_relu_bits<4>(bits_at(a.num_layers));
+      const ReluBits<4> mb = load_relu_bits<4>(bits_at(P.num_layers));
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[4];
       zero_acc<4>(acc);
-      gemm_mode<MODE, 4>(acc, pk + a.L.wT_rgb, pk + a.L.hT_rgb, X, 4, ln);
+      gemm_mode<MODE, 4>(acc, pk + P.L.wT_rgb, pk + P.L.hT_rgb, X, 4, ln);
       store_masked_bits<4, SBF>(acc, X, mb, h, (valid && a.gout.da_mid) ? row_ptr<SBF>(a.gout.da_mid, pc * 128) : nullptr);
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + a.L.wT_mid_x, pk + a.L.hT_mid_x, X, 16, ln);
+      gemm_mode<MODE, NB>(acc, pk + P.L.wT_mid_x, pk + P.L.hT_mid_x, X, 16, ln);
       store_act<NB, NB, false, SBF>(acc, X, (valid && a.gout.d_bott) ? row_ptr<SBF>(a.gout.d_bott, pc * W) : nullptr, h);
     }
     // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
@@ -189,7 +218,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
         if (h == 0) {
           const float raw = a.fwd.raw_density[pc];
           const float gs = a.gin.sigma ? a.gin.sigma[pc] * live : 0.0f;
-          q0.x = gs * sigmoid_f(raw + a.density_bias);  // softplus'
+          q0.x = gs * sigmoid_f(raw + P.density_bias);  // softplus'
           // predicted normal: pn = normalize(-normalize(n_raw)); G = g_pn + g_ndd * dir
           float dir[3], G[3] = {0.0f, 0.0f, 0.0f};
           const long long ray = pc / a.S;
@@ -241,26 +270,26 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
         *reinterpret_cast<float4*>(a.gout.dz_heads + pc * 16 + 4 * h) = q0;
         *reinterpret_cast<float4*>(a.gout.dz_heads + pc * 16 + 8 + 4 * h) = q1;
       }
-      const int l = a.num_layers - 1;
+      const int l = P.num_layers - 1;
       const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l));
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + a.L.wT_bh, pk + a.L.hT_bh, X, NB * 4 + 4, ln);
+      gemm_mode<MODE, NB>(acc, pk + P.L.wT_bh, pk + P.L.hT_bh, X, NB * 4 + 4, ln);
       store_masked_bits<NB, SBF>(acc, X, mb, h, valid ? row_ptr<SBF>(a.gout.dy, (long long)l * a.act_stride + pc * W) : nullptr);
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
     f32x16 eacc[4];
     zero_acc<4>(eacc);
 #pragma unroll 1
-    for (int l = a.num_layers - 1; l >= 1; --l) {
-      if (a.need_input_grad && l == a.skip_layer)
-        gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc_skip, pk + a.L.hT_enc_skip, X, NB * 4, ln);
+    for (int l = P.num_layers - 1; l >= 1; --l) {
+      if (a.need_input_grad && l == P.skip_layer)
+        gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc_skip, pk + P.L.hT_enc_skip, X, NB * 4, ln);
       const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l - 1));
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + a.L.wT_x[l], pk + a.L.hT_x[l], X, NB * 4, ln);
+      gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln);
 #ifdef RSN_BWD_NO_DYSTORE  // timing diagnostic (RSN_DIAG_BUILD only, tools/train_diag.sh): wrong results
       store_masked_bits<NB, SBF>(acc, X, mb, h, nullptr);
 #else
@@ -269,7 +298,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
     if (a.need_input_grad) {
-      gemm_mode<MODE, 4>(eacc, pk + a.L.wT_enc0, pk + a.L.hT_enc0, X, NB * 4, ln);
+      gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln);
       store_act<4, 4, false>(eacc, X);  // d loss / d encoded input, slot order
       const float* encp = a.saved.enc + pc * RSN_K_ENC_PAD;
       float dvar[3];
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
         float part = 0.0f;
 #pragma unroll 2
         for (int jj = 0; jj < 8; ++jj) {
-          const float f = h ? a.freqs[8 + jj] : a.freqs[jj];
+          const float f = h ? P.freqs[8 + jj] : P.freqs[jj];
           const int u = c * 8 + jj, u2 = u + 24;
           const float gs = Xf[(u >> 2) * 256 + (u & 3)], gc = Xf[(u2 >> 2) * 256 + (u2 & 3)];
           const float fs = encp[(u >> 2) * 8 + 4 * h + (u & 3)], fc = encp[(u2 >> 2) * 8 + 4 * h + (u2 & 3)];
@@ -310,39 +339,48 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdArgs a) {
   }
 }
 
-static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
-  int rc = rsn_compute_layout(d, &a.L);
+static int launch_bwd_jobs(const rsn_field_desc* d, BwdArgs* js, int n, void* stream) {
+  RSN_REQUIRE(n >= 1 && n <= RSN_MAX_JOBS, RSN_ERR_INVALID_ARGUMENT, "n_jobs=%d (1..%d)", n, RSN_MAX_JOBS);
+  BwdJobs J = {};
+  int rc = rsn_compute_layout(d, &J.s.L);
   if (rc != RSN_OK) return rc;
-  RSN_REQUIRE(a.packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "packed weights pointer is NULL");
-  RSN_REQUIRE(a.saved.relu_bits && a.saved.heads && a.gout.dy, RSN_ERR_INVALID_ARGUMENT,
-              "saved relu_bits / heads and gout.dy are required");
-  RSN_REQUIRE(!a.need_input_grad || (a.saved.enc && a.gout.d_input), RSN_ERR_INVALID_ARGUMENT,
-              "need_input_grad needs saved.enc and gout.d_input");
-  RSN_REQUIRE(a.mode == RSN_MODE_INF || (a.fwd.raw_density && a.fwd.diff && a.fwd.tint), RSN_ERR_INVALID_ARGUMENT,
-              "forward values raw_density/diff/tint are required");
-  RSN_REQUIRE(!(a.gin.ray_pn_loss || a.gin.ray_ori_loss) || (a.mode == RSN_MODE_FRUSTUM && a.gin.weights),
-              RSN_ERR_INVALID_ARGUMENT, "fused normal losses need the level's weights (frustum levels only)");
-  RSN_REQUIRE(!a.gin.ray_pn_loss || (a.saved.normals && a.fwd.pred_normals), RSN_ERR_INVALID_ARGUMENT,
-              "ray_pn_loss needs saved.normals and the forward pred_normals");
-  RSN_REQUIRE(!a.gin.ray_ori_loss || a.fwd.n_dot_d, RSN_ERR_INVALID_ARGUMENT, "ray_ori_loss needs the forward n_dot_d");
-  a.num_layers = d->num_layers;
-  a.skip_layer = d->skip_layer;
-  a.density_bias = d->density_bias;
-  for (int i = 0; i < RSN_NUM_FREQS; ++i) a.freqs[i] = d->freqs[i];
-  if (a.n_rays <= 0) return RSN_OK;
-  const long long n_points = (long long)a.n_rays * a.S;
-  a.act_stride = n_points * (long long)d->width;
-  const long long n_tiles = (n_points + 127) / 128;
+  RSN_REQUIRE(js[0].packed != nullptr, RSN_ERR_INVALID_ARGUMENT, "packed weights pointer is NULL");
+  J.s.packed = js[0].packed;
+  J.s.num_layers = d->num_layers;
+  J.s.skip_layer = d->skip_layer;
+  J.s.density_bias = d->density_bias;
+  for (int i = 0; i < RSN_NUM_FREQS; ++i) J.s.freqs[i] = d->freqs[i];
+  long long n_tiles = 0;
+  for (int k = 0; k < n; ++k) {
+    BwdArgs& a = js[k];
+    RSN_REQUIRE(a.saved.relu_bits && a.saved.heads && a.gout.dy, RSN_ERR_INVALID_ARGUMENT,
+                "job %d: saved relu_bits / heads and gout.dy are required", k);
+    RSN_REQUIRE(!a.need_input_grad || (a.saved.enc && a.gout.d_input), RSN_ERR_INVALID_ARGUMENT,
+                "job %d: need_input_grad needs saved.enc and gout.d_input", k);
+    RSN_REQUIRE(a.mode == RSN_MODE_INF || (a.fwd.raw_density && a.fwd.diff && a.fwd.tint), RSN_ERR_INVALID_ARGUMENT,
+                "job %d: forward values raw_density/diff/tint are required", k);
+    RSN_REQUIRE(!(a.gin.ray_pn_loss || a.gin.ray_ori_loss) || (a.mode == RSN_MODE_FRUSTUM && a.gin.weights),
+                RSN_ERR_INVALID_ARGUMENT, "job %d: fused normal losses need the level's weights (frustum levels only)", k);
+    RSN_REQUIRE(!a.gin.ray_pn_loss || (a.saved.normals && a.fwd.pred_normals), RSN_ERR_INVALID_ARGUMENT,
+                "job %d: ray_pn_loss needs saved.normals and the forward pred_normals", k);
+    RSN_REQUIRE(!a.gin.ray_ori_loss || a.fwd.n_dot_d, RSN_ERR_INVALID_ARGUMENT, "job %d: ray_ori_loss needs the forward n_dot_d", k);
+    if (a.n_rays <= 0) continue;
+    const long long n_points = (long long)a.n_rays * a.S;
+    a.act_stride = n_points * (long long)d->width;
+    n_tiles += (n_points + 127) / 128;
+    J.j[J.n_jobs++] = static_cast<const BwdJob&>(a);
+  }
+  if (J.n_jobs == 0) return RSN_OK;
   const int cached_cus = rsn_device_cus();
   const long long grid = n_tiles < (long long)cached_cus ? n_tiles : (long long)cached_cus;
   hipStream_t st = (hipStream_t)stream;
   const bool x6 = d->mma_mode == RSN_MMA_BF16X6;  // fp32-emulating split-bf16 sweeps (opt-in); else exact fp32
 #define RSN_LAUNCH_BWD(NBV)                                                                                  \
   do {                                                                                                       \
-    if (x6) hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
+    if (x6) hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 1>), dim3((unsigned)grid), dim3(256), 0, st, J);    \
     else if (d->mma_mode == RSN_MMA_BF16)  /* reduced-precision training sweeps (bf16 operands, fp32 accumulate) */ \
-      hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);              \
-    else hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 0>), dim3((unsigned)grid), dim3(256), 0, st, a);       \
+      hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 3>), dim3((unsigned)grid), dim3(256), 0, st, J);              \
+    else hipLaunchKernelGGL((rsn_field_bwd_kernel<NBV, 0>), dim3((unsigned)grid), dim3(256), 0, st, J);       \
   } while (0)
   switch (d->width) {
     case 256: RSN_LAUNCH_BWD(8); break;
@@ -353,6 +391,40 @@ static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) {
 #undef RSN_LAUNCH_BWD
   RSN_HIP(hipGetLastError());
   return RSN_OK;
+}
+
+static int launch_bwd(const rsn_field_desc* d, BwdArgs& a, void* stream) { return launch_bwd_jobs(d, &a, 1, stream); }
+
+// rsn_field_backward_jobs: the backward sweeps of several evaluations of the same field in one launch.
+extern "C" int rsn_field_backward_jobs(const rsn_field_desc* desc, const float* packed, int32_t n_jobs,
+                                       const rsn_field_bwd_job* jobs, void* stream) {
+  RSN_REQUIRE(desc && jobs, RSN_ERR_INVALID_ARGUMENT, "desc/jobs is NULL");
+  RSN_REQUIRE(n_jobs >= 1 && n_jobs <= RSN_MAX_JOBS, RSN_ERR_INVALID_ARGUMENT, "n_jobs=%d (1..%d)", n_jobs, RSN_MAX_JOBS);
+  BwdArgs js[RSN_MAX_JOBS] = {};
+  for (int k = 0; k < n_jobs; ++k) {
+    const rsn_field_bwd_job& q = jobs[k];
+    BwdArgs& a = js[k];
+    RSN_REQUIRE(q.kind == 0 || q.kind == 1, RSN_ERR_INVALID_ARGUMENT, "job %d: kind=%d", k, q.kind);
+    RSN_REQUIRE(q.n_rays >= 0 && q.saved && q.gout, RSN_ERR_INVALID_ARGUMENT, "job %d: n_rays / saved / gout", k);
+    a.packed = packed;
+    a.n_rays = q.n_rays; a.n_dev = q.n_dev; a.need_input_grad = q.need_input_grad;
+    a.saved = *q.saved; a.gout = *q.gout;
+    if (q.kind == 0) {
+      RSN_REQUIRE(q.n_samples >= 1 && q.fwd && q.gin, RSN_ERR_INVALID_ARGUMENT, "job %d: n_samples / fwd / gin", k);
+      RSN_REQUIRE(q.n_rays == 0 || (q.origins && q.directions && q.pixel_area && q.euclid_bins), RSN_ERR_INVALID_ARGUMENT,
+                  "job %d: a ray input pointer is NULL", k);
+      a.mode = RSN_MODE_FRUSTUM; a.S = q.n_samples;
+      a.origins = q.origins; a.directions = q.directions; a.pixel_area = q.pixel_area; a.bins = q.euclid_bins;
+      a.gin = *q.gin; a.fwd = *q.fwd;
+    } else {
+      RSN_REQUIRE(q.n_rays == 0 || (q.directions && q.sqradius && q.g_rgb), RSN_ERR_INVALID_ARGUMENT,
+                  "job %d: an input pointer is NULL", k);
+      a.mode = RSN_MODE_INF; a.S = 1;
+      a.directions = q.directions; a.sqradius = q.sqradius;
+      a.gin.color = q.g_rgb;
+    }
+  }
+  return launch_bwd_jobs(desc, js, n_jobs, stream);
 }
 
 extern "C" int rsn_field_backward_frustum(const rsn_field_desc* desc, const float* packed, int32_t n_rays,

@@ -3,12 +3,17 @@
 #pragma once
 #include "rsn_mfma.h"
 
-struct FieldArgs {
+// What every evaluation of one launch shares (the network) ...
+struct FieldShared {
   const float* packed;
   RsnPackedLayout L;
   int num_layers, skip_layer, width;
   float density_bias;
   float freqs[RSN_NUM_FREQS];
+};
+
+// ... and what one evaluation ("job") brings: its points, inputs and outputs.
+struct FieldJob {
   int mode;
   int n_rays;          // rays (frustum / inf) or points (gauss)
   const int* n_dev;    // optional device-side ray count
@@ -27,7 +32,22 @@ struct FieldArgs {
   const float* rough_in;      // RSN_MODE_EMB: optional explicit roughness for the SH attenuation (get_mid's argument)
   rsn_field_saved saved;      // training: activations kept for the backward pass (all NULL in eval)
   long long act_stride;       // floats between consecutive layers in saved.act (= n_points_max * W)
+};
+
+// one evaluation per launch (the plain-bf16 eval kernels of rsn_field_bf16.hip)
+struct FieldArgs : FieldShared, FieldJob {
   int stagger;                // rsn_field_bf16_ring_kernel: start delay of the second workgroup per CU (x s_sleep 127)
+};
+
+// Several evaluations in ONE launch of rsn_field_kernel: the tiles of job 0, then job 1, ... form one tile space that
+// the persistent workgroups stride through.  The reflect branch of a training step has three evaluations of a few
+// hundred to ~1,250 tiles each on 256 workgroups; launched one by one, each wastes its last partial round of tiles
+// (0.3-0.5 ms a round) and get_inf_color's ~20 tiles occupy 20 CUs for a whole launch.
+#define RSN_MAX_JOBS 3
+struct FieldJobs {
+  FieldShared s;
+  int n_jobs;
+  FieldJob j[RSN_MAX_JOBS];
 };
 
 // Conical frustum -> Gaussian (nerfstudio conical_frustum_to_gaussian / compute_3d_gaussian, N3),

@@ -236,6 +236,44 @@ def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], ne
     return gout
 
 
+def _reflect_field_backward(field, rays2, sq, levels, inf_saved, g_bg, n_dev, R: int):
+    """The three backward sweeps of the reflect branch in ONE launch (rsn_field_backward_jobs): the two reflect levels
+    (`levels`: [(euclid bins, level dict, upstream colour gradient, S)]) and get_inf_color (upstream: g_bg, the background
+    gradient both levels' compositing backward accumulated).  -> ([gout per level], gout of get_inf_color)."""
+    lib = _abi.load_library()
+    o, d, pa = rays2
+    dev = o.device
+    keep = []  # ctypes structures the job table points into
+    jobs = (_abi.FieldBwdJob * (len(levels) + 1))()
+    gouts, dev_work = [], []
+    for k, (eb, lv, g_color, S) in enumerate(levels):
+        gout, gst = _alloc_gout(field, R * S, dev, True)
+        gi = FieldGradsIn()
+        gi.color = ptr(g_color)
+        fo, fs = ops.field_outputs_struct(lv), _saved_struct(lv["saved"])
+        keep += [gst, gi, fo, fs]
+        j = jobs[k]
+        j.kind, j.n_rays, j.n_dev, j.n_samples, j.need_input_grad = 0, R, n_dev.data_ptr(), S, 1
+        j.origins, j.directions, j.pixel_area, j.euclid_bins = o.data_ptr(), d.data_ptr(), pa.data_ptr(), eb.data_ptr()
+        j.fwd, j.saved, j.gin, j.gout = C.pointer(fo), C.pointer(fs), C.pointer(gi), C.pointer(gst)
+        gouts.append(gout)
+        dev_work.append((n_dev, S))
+    gout_inf, gst_inf = _alloc_gout(field, R, dev, True)
+    fs_inf = _saved_struct(inf_saved)
+    keep += [gst_inf, fs_inf]
+    j = jobs[len(levels)]
+    j.kind, j.n_rays, j.n_dev, j.n_samples, j.need_input_grad = 1, R, n_dev.data_ptr(), 1, 1
+    j.directions, j.sqradius, j.g_rgb = d.data_ptr(), sq.data_ptr(), g_bg.data_ptr()
+    j.saved, j.gout = C.pointer(fs_inf), C.pointer(gst_inf)
+    dev_work.append((n_dev, 1))
+    desc = field.field_desc()
+    pk = field.packed_weights()
+    ops.timed("field_backward_input", {"points": 0, "points_dev": dev_work}, lambda: check(
+        lib.rsn_field_backward_jobs(C.byref(desc), ptr(pk), len(levels) + 1, jobs, ops._stream())))
+    del keep
+    return gouts, gout_inf
+
+
 def _ray_sum(x: Tensor, n: int, S: int, n_dev=None) -> Tensor:
     lib = _abi.load_library()
     out = torch.zeros(n, device=x.device)  # rows behind a device-side count stay zero
@@ -368,21 +406,13 @@ class GetOutputsTrain(torch.autograd.Function):
         M = int(nm.item()) if (jitter or bins) else None
         o2, d2, pa2, sq = rs["origins2"], rs["directions2"], rs["pixel_area2"], rs["sqradius"]
         near2, far2 = rs["nears2"], rs["fars2"]
-        f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
-        # get_inf_color in training mode (activations saved)
-        inf_saved = fld.alloc_saved(R, dev)
-        bg = f(R, 3)
-        desc = fld.field_desc()
-        fs = _saved_struct(inf_saved)
-        pk = fld.packed_weights()
+        # reflect-coarse level and get_inf_color (the composites' background, model.py:290): both depend only on the
+        # secondary rays and run as two jobs of ONE launch (rsn_field_forward_train_jobs)
         # launches sized for R rays do the work of M: the timer resolves the device-side count when it reads its events
-        work_inf, work_rc, work_rf = ({"points": 0, "points_dev": [(nm, k)]} for k in (1, Src, Srf))
-        ops.timed("field_forward_train", work_inf, lambda: check(
-            lib.rsn_field_forward_inf_train(C.byref(desc), ptr(pk), R, ptr(nm), ptr(d2), ptr(sq), ptr(bg), C.byref(fs),
-                                            ops._stream())))
+        work_rc, work_rf = ({"points": 0, "points_dev": [(nm, k)]} for k in (Src + 1, Srf))
         sb_rc, eb_rc = level_bins("reflect_coarse", R, Src, lambda: ops.sample_spaced(
             R, nm, Src, rec.spacing, rec.tan, near2, far2, jit("reflect_coarse", R, Src, rs["ray_index"], M)), M)
-        lrc = fld.evaluate_frustums_train(o2, d2, pa2, eb_rc, n_dev=nm, want_normals=False, work=work_rc)
+        lrc, bg, inf_saved = fld.evaluate_reflect_train(o2, d2, pa2, eb_rc, nm, sq, work=work_rc)
         crc = ops.composite(R, nm, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
         ops.reflect_combine(R, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
         sb_rf, eb_rf = level_bins("reflect_fine", R, Srf, lambda: ops.sample_pdf(
@@ -457,6 +487,7 @@ class GetOutputsTrain(torch.autograd.Function):
         nm = rs["n_masked"]
         g_bg = torch.zeros(R, 3, device=dev)
         g_pa2 = torch.zeros(R, device=dev)
+        jobs = []
         for eb, lv, cp, g_out, S in ((st["eb_rf"], st["lrf"], st["crf"], g_refl_f, Srf),
                                      (st["eb_rc"], st["lrc"], st["crc"], g_refl_c, Src)):
             g_comp = torch.empty(R, 3, device=dev)
@@ -465,18 +496,13 @@ class GetOutputsTrain(torch.autograd.Function):
             cb = _composite_backward(R, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
                                      want_bg=True, n_dev=nm)
             g_bg += cb["g_bg"]
-            gout = _field_backward(fld, st["rays2"], eb, lv, {"color": cb["g_color"]}, need_input=True, n_dev=nm,
-                                   work={"points": 0, "points_dev": [(nm, S)]})
-            g_pa2 += _ray_sum(gout["d_input"], R, S, nm)
-            pending.append((lv["saved"], gout, True, (nm, S)))
-        # get_inf_color
-        gout, gst = _alloc_gout(fld, R, dev, True)
-        desc = fld.field_desc()
-        fs = _saved_struct(st["inf_saved"])
-        pk = fld.packed_weights()
-        ops.timed("field_backward_input", {"points": 0, "points_dev": [(nm, 1)]}, lambda: check(
-            lib.rsn_field_backward_inf(C.byref(desc), ptr(pk), R, ptr(nm), ptr(st["rays2"][1]), ptr(st["sq"]),
-                                       C.byref(fs), ptr(g_bg), C.byref(gst), 1, ops._stream())))
+            jobs.append((eb, lv, cb["g_color"], S))
+        # the sweeps of both levels and of get_inf_color (whose upstream gradient g_bg is complete now) in ONE launch:
+        # their tiles share the persistent workgroups' rounds (rsn_field_backward_jobs)
+        gouts, gout = _reflect_field_backward(fld, st["rays2"], st["sq"], jobs, st["inf_saved"], g_bg, nm, R)
+        for (eb, lv, _g, S), go in zip(jobs, gouts):
+            g_pa2 += _ray_sum(go["d_input"], R, S, nm)
+            pending.append((lv["saved"], go, True, (nm, S)))
         pending.append((st["inf_saved"], gout, False, (nm, 1)))
         g_r = torch.empty(R, device=dev)  # the kernel zero-fills the rays that are not reflected
         check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
