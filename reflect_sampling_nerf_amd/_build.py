@@ -51,9 +51,11 @@ def _compile_one(hipcc, src, obj, flags, verbose):
     os.replace(obj + ".tmp", obj)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: str = LIB_PATH) -> str:
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: str = LIB_PATH,
+                  extra_sources=()) -> str:
     """Compile the HIP sources into librsn_hip.so; returns its path.  `force` recompiles every object.
-    extra_flags / lib_path: diagnostic variants (tools/) build a second library beside the product one."""
+    extra_flags / lib_path / extra_sources (absolute paths of further .hip files): diagnostic variants (tools/) build a
+    second library beside the product one."""
     if not force and not extra_flags and lib_path == LIB_PATH and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -65,9 +67,9 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), li
     os.makedirs(obj_dir, exist_ok=True)
     hdr = _headers()
     jobs, objs = [], []
-    for s in SOURCES:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
+    for s in [*SOURCES, *extra_sources]:
+        src = s if os.path.isabs(s) else os.path.join(CSRC, s)
+        obj = os.path.join(obj_dir, os.path.basename(s).replace(".hip", ".o"))
         stamp = obj + ".sha"
         want = _digest([src, *hdr], " ".join(flags))
         have = open(stamp).read() if os.path.exists(stamp) and os.path.exists(obj) else ""
