@@ -151,7 +151,9 @@ def train_step(model, ray_bundle, batch, optimizer, reducer: Optional[FlatGradAl
 
     ray_chunk: bound the step's activation memory.  The training forward keeps ~10.4 KB per sample for the backward
     pass and the backward sweep writes ~9.8 KB per sample of layer gradients for the weight-gradient kernels (DESIGN
-    4.3): ~28 GB at 4096 rays x (128 + 128 + reflect) and proportionally more for larger batches.  With ray_chunk = n
+    4.3; half of that in the bf16 mode).  The reflect branch's buffers are sized for ALL R rays whatever the number M of
+    reflected ones is (its launches take M from device memory, the host never reads it): 30.2 GB peak at 4096 rays x
+    (128 + 128 + reflect 64 + 64) in fp32, 15.9 GB in the bf16 mode, proportionally more for larger batches.  With ray_chunk = n
     the batch is walked in chunks of n rays -- forward, loss, backward per chunk, the parameter gradients ACCUMULATING
     (autograd adds into .grad; the weight-gradient kernels accumulate anyway) -- so the live activations are those of one
     chunk whatever the batch size.  The result is the whole-batch step exactly: the four MSE terms are means over the
