@@ -1,10 +1,10 @@
 """One training step of a rocprofv3 kernel trace (tools/profile_round.sh <tag>): span, busy and idle time, the field /
 weight-gradient launches in order, and the small launches grouped by kernel.
     python tools/step_timeline.py gpurun_out/prof_r03_train > profiles/r03_step_timeline.txt"""
-import collections, csv, glob, sys
+import collections, csv, glob, os, sys
 
 src = sys.argv[1]
-f = glob.glob(src + "/stats/*/*_kernel_trace.csv")[0]
+f = max(glob.glob(src + "/stats/*/*_kernel_trace.csv"), key=os.path.getmtime)  # newest run (gpurun merges into old directories)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "rsn_radam" in r["Kernel_Name"]]
 step = rows[idx[-2] + 1: idx[-1] + 1]  # the last complete step: behind one RAdam launch up to and including the next

@@ -24,4 +24,4 @@ for n_out, k_in in ((256, 256), (128, 256), (256, 104)):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         gb = n * (n_out * d.element_size() + k_in * xx.element_size()) / 1e9
-        print("%3d x %3d over %d points, %-16s %7.1f us  %5.2f GB  %5.2f TB/s" % (n_out, k_in, n, name, us, gb, gb / us * 1e-3 * 1e3))
+        print("%3d x %3d over %d points, %-16s %7.1f us  %5.2f GB  %5.2f TB/s" % (n_out, k_in, n, name, us, gb, gb / us * 1e3))
