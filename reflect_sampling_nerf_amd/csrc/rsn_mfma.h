@@ -360,6 +360,26 @@ __device__ __forceinline__ void put4(float* save, int off, const float4 v) {
   }
 }
 
+#ifdef RSN_DIAG_STORE_PATTERN
+// DIAGNOSTIC (wrong data placement, same bytes): what the saved-row stores would cost with other address patterns.
+// The product pattern writes, per instruction, 32 rows x 32 B.  1: 8 rows x one full 128-B line (8 consecutive lanes per
+// row).  2: 8 rows x 32 B per 16 lanes, the four 16-lane groups on the four 32-B quarters of the same 8 lines (what an
+// LDS read-back without bank conflicts could feed).  `ld` = row length in elements.
+template <bool SBF>
+__device__ __forceinline__ void put4_pat(float* save, int nb, int q, int ld, const float4 v) {
+  const int L = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if RSN_DIAG_STORE_PATTERN == 1
+  const int pr = 8 * q + (L >> 3), c = L & 7;
+#else
+  const int pr = 8 * q + (L & 7), c = 2 * (L >> 4) + ((L >> 3) & 1);
+#endif
+  put4<SBF>(save, (pr - (L & 31)) * ld + nb * 32 + 4 * c, v);
+}
+#define RSN_PUT4(SBF, save, nb, q, h, ld, v) put4_pat<SBF>(save, nb, q, ld, v)
+#else
+#define RSN_PUT4(SBF, save, nb, q, h, ld, v) put4<SBF>(save, ((nb) * 4 + (q)) * 8 + 4 * (h), v)
+#endif
+
 // ReLU sign bits of one lane: bit nb*16 + r = (accumulator register r of block nb, the layer's pre-activation) > 0,
 // packed into NBO/2 words (rsn_field_saved.relu_bits).  The dX sweeps mask by these bits instead of re-reading the
 // saved fp32 activations (1 KiB per point and layer -> 32 B; 124 fewer live registers in the sweeps).
@@ -430,7 +450,7 @@ __device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], floa
       v.z = __uint_as_float(__float_as_uint(acc[nb][4 * q + 2]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 2, 1));
       v.w = __uint_as_float(__float_as_uint(acc[nb][4 * q + 3]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 3, 1));
       xl[(nb * 4 + q) * 64] = v;
-      if (save) put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
+      if (save) RSN_PUT4(SBF, save, nb, q, h, NBO * 32, v);
     }
 }
 
@@ -457,7 +477,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
         v.w = relu_f(v.w);
       }
       xl[(nb * 4 + q) * 64] = v;
-      if (save) put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
+      if (save) RSN_PUT4(SBF, save, nb, q, h, NBS * 32, v);
     }
   }
   if (RELU && bits) {
@@ -494,7 +514,7 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, f
         v.w = relu_f(v.w);
       }
       xl[(nb * 4 + q) * 64] = v;
-      if (save) put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
+      if (save) RSN_PUT4(SBF, save, nb, q, h, NBO * 32, v);
       const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
       acc[nb][4 * q + 0] = bv.x;
       acc[nb][4 * q + 1] = bv.y;
