@@ -354,9 +354,19 @@ template <bool SBF>
 __device__ __forceinline__ void put4(float* save, int off, const float4 v) {
   if (SBF) {
     const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+#ifdef RSN_NT_STORES
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(save) + off));
+#else
     *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(save) + off) = o;
+#endif
   } else {
+#ifdef RSN_NT_STORES
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const f32x4v o = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4v*>(save + off));
+#else
     *reinterpret_cast<float4*>(save + off) = v;
+#endif
   }
 }
 
