@@ -17,8 +17,16 @@ REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(REPO, "build", "obj")
 LIB_PATH = os.path.join(PKG_DIR, "librsn_hip.so")
-SOURCES = ["rsn_pack.hip", "rsn_field.hip", "rsn_field_bf16.hip", "rsn_field_bwd.hip", "rsn_wgrad.hip", "rsn_render.hip", "rsn_train_ops.hip"]
+SOURCES = ["rsn_pack.hip", "rsn_field.hip", "rsn_field_split.hip", "rsn_field_bf16.hip", "rsn_field_bwd.hip", "rsn_wgrad.hip", "rsn_render.hip", "rsn_train_ops.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17"]
+# Per-file flags on top of FLAGS.  -amdgpu-mfma-vgpr-form: MFMA accumulators in architected VGPRs instead of AGPRs.  The
+# field kernels' layer epilogues read every accumulator (ReLU, mask bits, LDS hand-off, saved rows) and re-load it with
+# the next bias: from AGPRs that is a v_accvgpr_read / _write per value (1,035 + 290 static copies in
+# rsn_field_kernel<8,true,0>, 512 registers, 132 B of scratch); in VGPR form 67 + 66, 357 registers, no scratch, and the
+# step's forward / backward sweeps run 1.4 % / 1.5 % faster (profiles/r03_vgpr_form.txt).  NOT for rsn_wgrad.hip: its
+# 256-accumulator kernels need the AGPR half of the file for them (605 spills in VGPR form).
+_MFMA_VGPR = ("-mllvm", "-amdgpu-mfma-vgpr-form")
+SOURCE_FLAGS = {"rsn_field.hip": _MFMA_VGPR, "rsn_field_bwd.hip": _MFMA_VGPR}
 
 
 def _headers():
@@ -37,7 +45,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "rsn.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "rsn.h"), os.path.abspath(__file__)]  # this file: the flags
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -52,11 +60,13 @@ def _compile_one(hipcc, src, obj, flags, verbose):
 
 
 def build_library(force: bool = False, verbose: bool = False, extra_flags=(), lib_path: str = LIB_PATH,
-                  extra_sources=()) -> str:
+                  extra_sources=(), source_flags=None) -> str:
     """Compile the HIP sources into librsn_hip.so; returns its path.  `force` recompiles every object.
-    extra_flags / lib_path / extra_sources (absolute paths of further .hip files): diagnostic variants (tools/) build a
-    second library beside the product one."""
-    if not force and not extra_flags and lib_path == LIB_PATH and not _stale():
+    extra_flags / lib_path / extra_sources (absolute paths of further .hip files) / source_flags (per-file flags replacing
+    SOURCE_FLAGS): diagnostic variants (tools/) build a second library beside the product one."""
+    if source_flags is None:
+        source_flags = SOURCE_FLAGS
+    if not force and not extra_flags and lib_path == LIB_PATH and source_flags is SOURCE_FLAGS and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -69,15 +79,17 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), li
     jobs, objs = [], []
     for s in [*SOURCES, *extra_sources]:
         src = s if os.path.isabs(s) else os.path.join(CSRC, s)
-        obj = os.path.join(obj_dir, os.path.basename(s).replace(".hip", ".o"))
+        sflags = [*flags, *source_flags.get(os.path.basename(s), ())]
+        stag = "" if len(sflags) == len(flags) else "." + hashlib.sha256(" ".join(sflags).encode()).hexdigest()[:8]
+        obj = os.path.join(obj_dir, os.path.basename(s).replace(".hip", stag + ".o"))
         stamp = obj + ".sha"
-        want = _digest([src, *hdr], " ".join(flags))
+        want = _digest([src, *hdr], " ".join(sflags))
         have = open(stamp).read() if os.path.exists(stamp) and os.path.exists(obj) else ""
         objs.append(obj)
         if force or have != want:
-            jobs.append((src, obj, stamp, want))
+            jobs.append((src, obj, stamp, want, sflags))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
-        futs = {ex.submit(_compile_one, hipcc, src, obj, flags, verbose): (stamp, want) for src, obj, stamp, want in jobs}
+        futs = {ex.submit(_compile_one, hipcc, src, obj, sflags, verbose): (stamp, want) for src, obj, stamp, want, sflags in jobs}
         for f in concurrent.futures.as_completed(futs):
             f.result()
             stamp, want = futs[f]

@@ -115,3 +115,5 @@ __device__ __forceinline__ void frustum_to_contracted(const float o[3], const fl
 
 // rsn_field_bf16.hip: the dedicated RSN_MMA_BF16 eval kernel (two workgroups per CU)
 int rsn_launch_field_bf16(int width, long long grid, hipStream_t st, const FieldArgs& a);
+// split-bf16 instantiations of rsn_field_kernel (rsn_field_split.hip); mode 1 = BF16X6, 2 = BF16X3 (eval only)
+int rsn_launch_field_split(int width, bool train, int mode, long long grid, hipStream_t st, const FieldJobs& J);

@@ -1,0 +1,425 @@
+// rsn_field_kernel.h -- the field kernel template (see rsn_field.hip for the layout argument), shared by two translation
+// units that differ in ONE compiler flag (reflect_sampling_nerf_amd/_build.py, SOURCE_FLAGS):
+//   rsn_field.hip        exact fp32 (MODE 0) and plain-bf16 training (MODE 3): MFMA accumulators in architected VGPRs
+//                        (-amdgpu-mfma-vgpr-form: the epilogues touch every accumulator; no v_accvgpr copies, no scratch);
+//   rsn_field_split.hip  split-bf16 (MODE 1, 2): hipcc's default AGPR accumulators -- these kernels also hold the bf16
+//                        triples of the operands, and in VGPR form their training forward runs 14 % slower.
+#pragma once
+#include "rsn_mfma.h"
+
+#include "rsn_field_common.h"
+
+// Optional per-phase cycle accounting (debug builds only: tools/phase_report.py compiles a second library with
+// -DRSN_PHASE_TIMERS).  Wave 0 of every workgroup sums shader-clock deltas per phase; never part of librsn_hip.so.
+// Only the kernels of rsn_field.hip (RSN_FIELD_MAIN_TU) carry the counters.
+#if defined(RSN_PHASE_TIMERS) && defined(RSN_FIELD_MAIN_TU)
+#define RSN_FIELD_TIMED 1
+__device__ unsigned long long rsn_phase_cycles[16];
+#define RSN_T(i)                                \
+  do {                                          \
+    __builtin_amdgcn_sched_barrier(0);          \
+    const long long tn_ = clock64();            \
+    tacc[i] += tn_ - tlast;                     \
+    tlast = tn_;                                \
+    __builtin_amdgcn_sched_barrier(0);          \
+  } while (0)
+#else
+#define RSN_T(i)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+template <int NB, bool TRAIN, int MODE>
+__global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
+  constexpr int XITS = (NB * 4 > 16) ? NB * 4 : 16;  // >= 14 (encoding, K=16 steps) and >= 16 (mid hidden)
+  constexpr int WAVE_F4 = (XITS + RSN_AUX_ITS) * 64;
+  constexpr int W = NB * 32;
+  constexpr bool SBF = TRAIN && MODE == 3;  // reduced-precision training: activations / bottleneck / mid hidden saved as bf16
+  __shared__ float4 smem[4 * WAVE_F4];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  float4* X = smem + wid * WAVE_F4 + lane;
+  float4* AUX = X + XITS * 64;
+  float* Xf = reinterpret_cast<float*>(X);
+
+  const FieldShared& P = J.s;
+  // the launch's tile space: job k owns tiles [tb_k, tb_k+1) of 128 points (its ray count may live on the device)
+  long long np0 = 0, np1 = 0, np2 = 0, tb1 = 0, tb2 = 0, n_tiles = 0;
+#pragma unroll
+  for (int k = 0; k < RSN_MAX_JOBS; ++k) {
+    if (k < J.n_jobs) {
+      int nr = J.j[k].n_rays;
+      if (J.j[k].n_dev) {
+        const int nd = *J.j[k].n_dev;
+        nr = nd < nr ? nd : nr;
+      }
+      const long long np = (long long)nr * J.j[k].S;
+      if (k == 0) np0 = np; else if (k == 1) np1 = np; else np2 = np;
+      n_tiles += (np + 127) / 128;
+    }
+    if (k == 0) tb1 = n_tiles; else if (k == 1) tb2 = n_tiles;
+  }
+  const float* __restrict__ pk = P.packed;
+#ifdef RSN_FIELD_TIMED
+  long long tacc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#endif
+
+  for (long long gtile = blockIdx.x; gtile < n_tiles; gtile += gridDim.x) {
+    const int jk = (gtile >= tb1 ? 1 : 0) + (gtile >= tb2 ? 1 : 0);  // workgroup-uniform
+    const FieldJob& a = J.j[jk];
+    const long long n_points = jk == 0 ? np0 : (jk == 1 ? np1 : np2);
+    const long long tile = gtile - (jk == 0 ? 0 : (jk == 1 ? tb1 : tb2));
+    const long long p0 = tile * 128 + wid * 32;
+    if (p0 >= n_points) continue;  // wave-uniform; waves never synchronise with each other
+    // an opaque copy of the lane id per tile: per-lane weight / output addresses are then not loop-invariant, so hipcc
+    // cannot hoist dozens of them out of the persistent tile loop and spill them to scratch
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int m = ln & 31, h = ln >> 5;
+    RSN_T(11);
+    const long long p = p0 + m;
+    const bool valid = p < n_points;
+    const long long pc = valid ? p : n_points - 1;
+    // training: this lane's slot in the ReLU bit masks of layer l (rsn_field_saved.relu_bits: [L+1][N][2][NB/2] words)
+    auto bits_at = [&](int l) -> unsigned* {
+      return a.saved.relu_bits + ((((long long)l * (a.act_stride / W)) + pc) * 2 + h) * (NB / 2 > 2 ? NB / 2 : 2);
+    };
+
+    float mc[3] = {0.0f, 0.0f, 0.0f}, vc[3] = {0.0f, 0.0f, 0.0f}, vd[3] = {0.0f, 0.0f, 0.0f};
+    bool has_cov = true, has_dir = true;
+    float4 wbh[NB + 1];  // first weight fragment of the bottleneck+heads GEMM
+    if (a.mode == RSN_MODE_EMB) {
+      pre_mode<MODE, NB + 1>(wbh, pk + P.L.w_bh, ln);
+      // granular Field API: heads / mid MLP on a caller-supplied embedding (field.py:139-186)
+      has_dir = a.view_dirs != nullptr;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vd[c] = has_dir ? a.view_dirs[pc * 3 + c] : 0.0f;
+#pragma unroll 4
+      for (int it = 0; it < NB * 4; ++it)
+        X[it * 64] = *reinterpret_cast<const float4*>(a.emb_in + pc * W + it * 8 + 4 * h);
+    } else {
+    // ---------------- encode -----------------
+    if (a.mode == RSN_MODE_FRUSTUM) {
+      const long long ray = pc / a.S;
+      const int s = (int)(pc - ray * a.S);
+      float o[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o[c] = a.origins[ray * 3 + c];
+        vd[c] = a.directions[ray * 3 + c];
+      }
+      const float pa = a.pixel_area[ray];
+      const float t0 = a.bins[ray * (a.S + 1) + s];
+      const float t1 = a.bins[ray * (a.S + 1) + s + 1];
+      frustum_to_contracted(o, vd, pa, t0, t1, mc, vc);
+    } else if (a.mode == RSN_MODE_INF) {
+      const float r2 = a.sqradius[pc];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        vd[c] = a.directions[pc * 3 + c];
+        mc[c] = 2.0f * vd[c];
+        vc[c] = (0.6f * r2) * (1.0f - vd[c] * vd[c]);
+      }
+      has_dir = false;  // SH inputs are zeroed (reflect_sampling_nerf_field.py:199)
+    } else {
+      has_cov = a.cov_diag != nullptr;
+      has_dir = a.view_dirs != nullptr;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        mc[c] = a.means[pc * 3 + c];
+        vc[c] = has_cov ? a.cov_diag[pc * 3 + c] : 0.0f;
+        vd[c] = has_dir ? a.view_dirs[pc * 3 + c] : 0.0f;
+      }
+    }
+
+    // integrated positional encoding (nerfstudio NeRFEncoding, N2): this lane produces the features of
+    // frequencies 8h..8h+7 into its own LDS slots (slot order: rsn_pack.hip cols_encoding).
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      const float x = (c == 0) ? mc[0] : (c == 1 ? mc[1] : mc[2]);
+      const float v = (c == 0) ? vc[0] : (c == 1 ? vc[1] : vc[2]);
+      const float sx = 6.283185307179586f * x;
+#pragma unroll 2
+      for (int jj = 0; jj < 8; ++jj) {
+        const float f = h ? P.freqs[8 + jj] : P.freqs[jj];
+        const float ang = sx * f;
+        const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
+        const float fs = e * sin_big(ang);
+        const float fc = e * sin_big(ang + 1.5707963267948966f);
+        const int u = c * 8 + jj;
+        Xf[(u >> 2) * 256 + (u & 3)] = fs;
+        Xf[((u + 24) >> 2) * 256 + ((u + 24) & 3)] = fc;
+      }
+    }
+    {
+      float4 raw = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (h == 0) raw = make_float4(mc[0], mc[1], mc[2], 0.0f);
+      X[12 * 64] = raw;
+      if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // K=16 steps read iteration 13 (zero weights)
+    }
+    // this lane's 52 encoded inputs, re-used by the skip layer.  Held as vector-typed SSA values (not an
+    // indexable array) so that they stay in the unified VGPR/AGPR file instead of scratch memory.
+    f32x16 st0, st1, st2;
+    float4 st3;
+    {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float4 t0 = X[it * 64], t1 = X[(4 + it) * 64], t2 = X[(8 + it) * 64];
+        st0[4 * it + 0] = t0.x; st0[4 * it + 1] = t0.y; st0[4 * it + 2] = t0.z; st0[4 * it + 3] = t0.w;
+        st1[4 * it + 0] = t1.x; st1[4 * it + 1] = t1.y; st1[4 * it + 2] = t1.z; st1[4 * it + 3] = t1.w;
+        st2[4 * it + 0] = t2.x; st2[4 * it + 1] = t2.y; st2[4 * it + 2] = t2.z; st2[4 * it + 3] = t2.w;
+      }
+      st3 = X[12 * 64];
+    }
+    if (TRAIN && a.saved.enc && valid) {  // [N,104] in slot order
+      float* row = a.saved.enc + pc * RSN_K_ENC_PAD;
+#pragma unroll
+      for (int it = 0; it < RSN_ENC_ITS; ++it) *reinterpret_cast<float4*>(row + it * 8 + 4 * h) = X[it * 64];
+    }
+
+    RSN_T(0);
+    // ---------------- trunk -----------------
+    {
+      f32x16 acc[NB];
+      float4 wpre[NB];  // first weight fragment of the next GEMM, fetched ahead of the epilogue in front of it
+      pre_mode<MODE, NB>(wpre, pk + P.L.w_enc0, ln);
+      init_acc<NB>(acc, pk + P.L.b[0], h);
+      RSN_T(1);
+      gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_enc0, pk + P.L.h_enc0, X, RSN_ENC_ITS, ln);
+      RSN_T(2);
+#pragma unroll 1
+      for (int l = 1; l < P.num_layers; ++l) {
+        pre_mode<MODE, NB>(wpre, pk + P.L.w_x[l], ln);
+        // ReLU between layers; the accumulators restart from layer l's bias
+        store_act_init<NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (l - 1) * a.act_stride + pc * W) : nullptr,
+                                 h, pk + P.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
+        RSN_T(3);
+        gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_x[l], pk + P.L.h_x[l], X, NB * 4, ln);
+        RSN_T(4);
+        if (l == P.skip_layer) {
+          pre_mode<MODE, NB>(wpre, pk + P.L.w_enc_skip, ln);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            X[it * 64] = make_float4(st0[4 * it], st0[4 * it + 1], st0[4 * it + 2], st0[4 * it + 3]);
+            X[(4 + it) * 64] = make_float4(st1[4 * it], st1[4 * it + 1], st1[4 * it + 2], st1[4 * it + 3]);
+            X[(8 + it) * 64] = make_float4(st2[4 * it], st2[4 * it + 1], st2[4 * it + 2], st2[4 * it + 3]);
+          }
+          X[12 * 64] = st3;
+          if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_enc_skip, pk + P.L.h_enc_skip, X, RSN_ENC_ITS, ln);
+          RSN_T(2);
+        }
+      }
+      // out_activation = ReLU
+      pre_mode<MODE, NB + 1>(wbh, pk + P.L.w_bh, ln);
+      store_act<NB, NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (P.num_layers - 1) * a.act_stride + pc * W) : nullptr, h,
+                              (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers - 1) : nullptr);
+      RSN_T(3);
+    }
+    }  // mode != RSN_MODE_EMB
+    if (a.embedding && valid) {
+#pragma unroll 4
+      for (int it = 0; it < NB * 4; ++it)
+        *reinterpret_cast<float4*>(a.embedding + pc * W + it * 8 + 4 * h) = X[it * 64];
+    }
+
+    // ---------------- bottleneck + heads (one GEMM, N = W + 32) -----------------
+    float dcol[3], tcol[3], rho;
+    float4 wmid[4];  // first weight fragment of mlp_mid's SH part
+    {
+      f32x16 acc[NB + 1];
+      init_acc<NB + 1>(acc, pk + P.L.b_bh, h);
+      RSN_T(1);
+      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + P.L.w_bh, pk + P.L.h_bh, X, NB * 4, ln);
+      RSN_T(5);
+      pre_mode<MODE, 4>(wmid, pk + P.L.w_mid_sh, ln);
+      const float r0 = acc[NB][0], r1 = acc[NB][1], r2 = acc[NB][2], r3 = acc[NB][3];
+      const float r4 = acc[NB][4], r5 = acc[NB][5], r6 = acc[NB][6];
+      // h == 0: r0 raw density, r1..r3 normals, r4 roughness.   h == 1: r0..r2 diff, r4..r6 tint.
+      const float rough_raw = __shfl(r4, m, 64);
+      rho = (a.mode == RSN_MODE_EMB && a.rough_in) ? a.rough_in[pc] : softplus_f(rough_raw);
+      dcol[0] = sigmoid_f(r0); dcol[1] = sigmoid_f(r1); dcol[2] = sigmoid_f(r2);
+      tcol[0] = sigmoid_f(r4); tcol[1] = sigmoid_f(r5); tcol[2] = sigmoid_f(r6);
+      if (a.mode != RSN_MODE_INF && valid) {
+        if (h == 0) {
+          // get_pred_normals: -normalize(head) then normalize again (field.py:139-144, N6)
+          float nrm = fmaxf(sqrtf(r1 * r1 + r2 * r2 + r3 * r3), 1e-12f);
+          float nx = -(r1 / nrm), ny = -(r2 / nrm), nz = -(r3 / nrm);
+          nrm = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);
+          nx /= nrm; ny /= nrm; nz /= nrm;
+          if (a.out.sigma) a.out.sigma[pc] = softplus_f(r0 + P.density_bias);
+          if (a.out.raw_density) a.out.raw_density[pc] = r0;
+          if (a.out.pred_normals) {
+            a.out.pred_normals[pc * 3 + 0] = nx;
+            a.out.pred_normals[pc * 3 + 1] = ny;
+            a.out.pred_normals[pc * 3 + 2] = nz;
+          }
+          if (a.out.n_dot_d) a.out.n_dot_d[pc] = vd[0] * nx + vd[1] * ny + vd[2] * nz;
+          if (a.out.roughness) a.out.roughness[pc] = sigmoid_f(r4);
+          if (a.out.raw_roughness) a.out.raw_roughness[pc] = r4;
+        } else {
+          if (a.out.diff) {
+            a.out.diff[pc * 3 + 0] = dcol[0]; a.out.diff[pc * 3 + 1] = dcol[1]; a.out.diff[pc * 3 + 2] = dcol[2];
+          }
+          if (a.out.tint) {
+            a.out.tint[pc * 3 + 0] = tcol[0]; a.out.tint[pc * 3 + 1] = tcol[1]; a.out.tint[pc * 3 + 2] = tcol[2];
+          }
+        }
+      }
+      if (TRAIN && a.saved.heads && valid && h == 0) {  // raw normal head (3) + raw roughness head
+        *reinterpret_cast<float4*>(a.saved.heads + pc * 8) = make_float4(r1, r2, r3, r4);
+      }
+      // bottleneck output (no activation) becomes the x-part of mlp_mid's input
+      store_act<NB + 1, NB, false, SBF>(acc, X, (TRAIN && a.saved.bott && valid) ? row_ptr<SBF>(a.saved.bott, pc * W) : nullptr, h);
+    }
+
+    // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
+    {
+      float sh[34];
+      if (has_dir) {
+        sh34_attenuated(vd[0], vd[1], vd[2], rho, sh);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 34; ++i) sh[i] = 0.0f;
+      }
+#pragma unroll
+      for (int it = 0; it < RSN_SH_ITS; ++it) {
+        float vals[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int u = it * 4 + s;
+          vals[s] = (u < 17) ? (h ? sh[17 + u] : sh[u]) : 0.0f;
+        }
+        AUX[it * 64] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+        if (MODE != 0 && it == 0) AUX[5 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (TRAIN && a.saved.sh && valid)
+          *reinterpret_cast<float4*>(a.saved.sh + pc * RSN_K_SH_PAD + it * 8 + 4 * h) =
+              make_float4(vals[0], vals[1], vals[2], vals[3]);
+      }
+    }
+
+    RSN_T(6);
+    // ---------------- mlp_mid + RGB head -----------------
+    float4 wrgb[1];
+    {
+      f32x16 accm[4];
+      init_acc<4>(accm, pk + P.L.b_mid, h);
+      RSN_T(1);
+      float4 wmx[4];
+      pre_mode<MODE, 4>(wmx, pk + P.L.w_mid_x, ln);
+      gemm_mode_run<MODE, 4>(accm, wmid, pk + P.L.w_mid_sh, pk + P.L.h_mid_sh, AUX, RSN_SH_ITS, ln);
+      RSN_T(7);
+      gemm_mode_run<MODE, 4>(accm, wmx, pk + P.L.w_mid_x, pk + P.L.h_mid_x, X, NB * 4, ln);
+      RSN_T(8);
+      pre_mode<MODE, 1>(wrgb, pk + P.L.w_rgb, ln);
+      store_act<4, 4, true, SBF>(accm, X, (TRAIN && a.saved.hid && valid) ? row_ptr<SBF>(a.saved.hid, pc * 128) : nullptr, h,
+                            (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers) : nullptr);
+      RSN_T(3);
+    }
+    {
+      f32x16 accr[1];
+      init_acc<1>(accr, pk + P.L.b_rgb, h);
+      RSN_T(1);
+      gemm_mode_run<MODE, 1>(accr, wrgb, pk + P.L.w_rgb, pk + P.L.h_rgb, X, 16, ln);
+      RSN_T(9);
+      if (h == 1 && valid) {
+        const float m0 = sigmoid_f(accr[0][0]);
+        const float m1 = sigmoid_f(accr[0][1]);
+        const float m2 = sigmoid_f(accr[0][2]);
+        if (TRAIN && a.saved.heads) *reinterpret_cast<float4*>(a.saved.heads + pc * 8 + 4) = make_float4(m0, m1, m2, 0.0f);
+        if (a.out.color) {
+          if (a.mode == RSN_MODE_INF || (a.mode == RSN_MODE_EMB && !a.out.diff && !a.out.tint)) {
+            a.out.color[pc * 3 + 0] = m0; a.out.color[pc * 3 + 1] = m1; a.out.color[pc * 3 + 2] = m2;
+          } else {
+            a.out.color[pc * 3 + 0] = dcol[0] + tcol[0] * m0;
+            a.out.color[pc * 3 + 1] = dcol[1] + tcol[1] * m1;
+            a.out.color[pc * 3 + 2] = dcol[2] + tcol[2] * m2;
+          }
+        }
+      }
+    }
+
+    RSN_T(10);
+    // ---------------- training: analytic normals = -normalize(d raw_density / d contracted mean) -----------------
+    // (reflect_sampling_nerf_field.py:125-127,146-147 -> nerfstudio Field.get_normals).  A dX-only sweep back
+    // through the trunk: seed = density-head row masked by the embedding's ReLU, then W_l^T GEMMs masked by the
+    // saved activations; the encoded-input gradient accumulates in 4 extra blocks (slot order), and the chain
+    // through sin(2 pi x f [+ pi/2]) * exp(-var f^2 / 2) is closed per lane (the covariance is a constant here,
+    // exactly like the reference, which sets requires_grad on the mean after contraction).
+    if (TRAIN && a.saved.normals && a.saved.relu_bits) {
+      const float* __restrict__ wd = pk + P.L.v_density;
+      {
+        // seed: the density-head row masked by the embedding's ReLU (bits of the last trunk layer)
+        const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(P.num_layers - 1));
+#pragma unroll
+        for (int it = 0; it < NB * 4; ++it) {
+          const float4 w = *reinterpret_cast<const float4*>(wd + it * 8 + 4 * h);
+          const int word = mb.w[it / 8];
+          const int base = ((it / 4) & 1) * 16 + 4 * (it & 3);
+          X[it * 64] = make_float4(
+              __uint_as_float(__float_as_uint(w.x) & bit_mask(word, base + 0)),
+              __uint_as_float(__float_as_uint(w.y) & bit_mask(word, base + 1)),
+              __uint_as_float(__float_as_uint(w.z) & bit_mask(word, base + 2)),
+              __uint_as_float(__float_as_uint(w.w) & bit_mask(word, base + 3)));
+        }
+      }
+      f32x16 eacc[4];
+      zero_acc<4>(eacc);
+      RSN_T(13);
+#pragma unroll 1
+      for (int l = P.num_layers - 1; l >= 1; --l) {
+        if (l == P.skip_layer) gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc_skip, pk + P.L.hT_enc_skip, X, NB * 4, ln);
+        const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[NB];
+        zero_acc<NB>(acc);
+        RSN_T(13);
+        gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln);
+        RSN_T(12);
+        store_masked_bits<NB>(acc, X, mb, h);
+      }
+      RSN_T(13);
+      gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln);
+      RSN_T(12);
+      store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
+      float nrm[3];
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) {
+        const float x = (c == 0) ? mc[0] : (c == 1 ? mc[1] : mc[2]);
+        const float v = (c == 0) ? vc[0] : (c == 1 ? vc[1] : vc[2]);
+        const float sx = 6.283185307179586f * x;
+        float part = 0.0f;
+#pragma unroll 2
+        for (int jj = 0; jj < 8; ++jj) {
+          const float f = h ? P.freqs[8 + jj] : P.freqs[jj];
+          const float ang = sx * f;
+          const float e = has_cov ? expf(-0.5f * (v * (f * f))) : 1.0f;
+          const int u = c * 8 + jj;
+          const float gs = Xf[(u >> 2) * 256 + (u & 3)];
+          const float gc = Xf[((u + 24) >> 2) * 256 + ((u + 24) & 3)];
+          part += (gs * (e * cos_big(ang)) + gc * (e * cos_big(ang + 1.5707963267948966f))) * f;
+        }
+        part *= 6.283185307179586f;
+        if (h == 0) part += Xf[12 * 256 + c];  // the raw-coordinate input column
+        const float tot = part + __shfl_xor(part, 32, 64);
+        if (c == 0) nrm[0] = tot; else if (c == 1) nrm[1] = tot; else nrm[2] = tot;
+      }
+      if (h == 0 && valid) {
+        const float len = fmaxf(sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]), 1e-12f);
+        a.saved.normals[pc * 3 + 0] = -(nrm[0] / len);
+        a.saved.normals[pc * 3 + 1] = -(nrm[1] / len);
+        a.saved.normals[pc * 3 + 2] = -(nrm[2] / len);
+      }
+      RSN_T(14);
+    }
+  }
+#ifdef RSN_FIELD_TIMED
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 15; ++i) atomicAdd(&rsn_phase_cycles[i], (unsigned long long)tacc[i]);
+    atomicAdd(&rsn_phase_cycles[15], 1ull);
+  }
+#endif
+}
+

@@ -443,6 +443,14 @@ __device__ __forceinline__ ReluBits<NBO> load_relu_bits(const unsigned* __restri
   return m;
 }
 
+// bit `pos` of `word` as 0 / 0xffffffff: one v_bfe_i32.  Written as (non-volatile) asm because hipcc rewrites
+// `x & sext(bit)` into v_and (test) + v_cmp_ne + v_cndmask: three VALU per value and a VCC hazard nop, where bfe + and is two.
+__device__ __forceinline__ unsigned bit_mask(int word, int pos) {
+  unsigned m;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(pos));
+  return m;
+}
+
 // dX-sweep epilogue on mask bits: X[it][lane] = bit ? acc : 0 (v_bfe_i32 gives 0 / -1, one v_and applies it);
 // optionally also stored to row `save` (backward pass: the layer's pre-activation gradient for the weight gradients)
 template <int NBO, bool SBF = false>
@@ -455,10 +463,10 @@ __device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], floa
       const int word = m.w[nb / 2];
       const int base = (nb & 1) * 16 + 4 * q;
       float4 v;
-      v.x = __uint_as_float(__float_as_uint(acc[nb][4 * q + 0]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 0, 1));
-      v.y = __uint_as_float(__float_as_uint(acc[nb][4 * q + 1]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 1, 1));
-      v.z = __uint_as_float(__float_as_uint(acc[nb][4 * q + 2]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 2, 1));
-      v.w = __uint_as_float(__float_as_uint(acc[nb][4 * q + 3]) & (unsigned)__builtin_amdgcn_sbfe(word, base + 3, 1));
+      v.x = __uint_as_float(__float_as_uint(acc[nb][4 * q + 0]) & bit_mask(word, base + 0));
+      v.y = __uint_as_float(__float_as_uint(acc[nb][4 * q + 1]) & bit_mask(word, base + 1));
+      v.z = __uint_as_float(__float_as_uint(acc[nb][4 * q + 2]) & bit_mask(word, base + 2));
+      v.w = __uint_as_float(__float_as_uint(acc[nb][4 * q + 3]) & bit_mask(word, base + 3));
       xl[(nb * 4 + q) * 64] = v;
       if (save) RSN_PUT4(SBF, save, nb, q, h, NBO * 32, v);
     }

@@ -2,7 +2,9 @@
 # Register / scratch / LDS usage of every kernel of one source file, from hipcc's resource-usage remarks.
 # Usage: tools/kernel_resources.sh rsn_field_bwd.hip [extra -D flags]
 SRC=$1; shift
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I include -I reflect_sampling_nerf_amd/csrc \
+# the per-file flags of reflect_sampling_nerf_amd/_build.py (SOURCE_FLAGS)
+PF=$(python3 -c "import sys; sys.path.insert(0, '.'); from reflect_sampling_nerf_amd._build import SOURCE_FLAGS; print(' '.join(SOURCE_FLAGS.get('$SRC', ())))")
+hipcc $PF -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I include -I reflect_sampling_nerf_amd/csrc \
   -Rpass-analysis=kernel-resource-usage -c reflect_sampling_nerf_amd/csrc/$SRC -o /dev/null "$@" 2>&1 |
   python3 -c '
 import re, sys
