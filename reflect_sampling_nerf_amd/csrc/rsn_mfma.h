@@ -98,18 +98,43 @@ __device__ __forceinline__ void sh34_attenuated(float x, float y, float z, float
   sh[33] = 0.72892666017482986f * (x2 * re7 - y2 * im7) * e8;
 }
 
-// ReLU as one v_med3_f32 (fmaxf would first canonicalise a possible sNaN: an extra v_max per element)
-__device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }
+// ReLU as ONE v_max_f32.  Written as (non-volatile) asm: from fmaxf / fmed3 hipcc emits v_max(x, x) first (it
+// canonicalises a possible sNaN), two VALU per value in every layer epilogue.  NaN -> 0, as before.
+__device__ __forceinline__ float relu_f(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
 
 // ------------------------------------------------------------------------------------------------
 // MFMA K loop: acc[nb] += W_seg[nb-block] * X, weights double-buffered in registers.
 // ------------------------------------------------------------------------------------------------
 // NBT = output blocks of the packed segment ([it][NBT][lane][4]); a wave that takes only NBO < NBT of them passes its
 // segment pointer already advanced to its first block (tools/probes/gemm_occ_probe.hip).
+// Weight fragments arrive through BUFFER loads: the segment base lives in a scalar buffer descriptor, the K-iteration in
+// the scalar offset, and a lane sends ONE 32-bit offset (lane * 16 + nb KiB, loop-invariant registers) instead of a
+// 64-bit address that a v_add_co pair advances per load.  The 64-bit-address form (global_load_dwordx4 v[lo:hi]) was the
+// "per-load cost" of rounds 1-2: with buffer loads the eval kernel went 4.90 -> 4.63 ms (83.8 -> 88.6 % of the fp32-MFMA
+// peak) and the training forward 22.5 -> 21.4 ms per step (76.6 -> 80.4 %), same box (profiles/r03_buffer_loads.txt).
+// Reads past the descriptor's 2 GiB window return 0 (never reached: a packed segment is < 1 MiB).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct WBuf {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;  // lane * 16
+};
+__device__ __forceinline__ WBuf wbuf_make(const float* __restrict__ wseg, int lane) {
+  WBuf b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wseg), 0, 0x7fffffff, 0x00020000);
+  b.voff = (unsigned)lane * 16u;
+  return b;
+}
 template <int NBO, int NBT = NBO>
-__device__ __forceinline__ void load_w(float4 (&w)[NBO], const float4* __restrict__ wp, int it) {
+__device__ __forceinline__ void load_w(float4 (&w)[NBO], const WBuf& b, int it) {
 #pragma unroll
-  for (int nb = 0; nb < NBO; ++nb) w[nb] = wp[(it * NBT + nb) * 64];
+  for (int nb = 0; nb < NBO; ++nb) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, b.voff + nb * 1024u, (unsigned)it * (NBT * 1024u), 0);
+    w[nb] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
 }
 
 template <int NBO>
@@ -148,13 +173,13 @@ __device__ __forceinline__ void interleave_loads() {
 // round trip hides under that epilogue.
 template <int NBO, int NBT = NBO>
 __device__ __forceinline__ void pre_w(float4 (&wa)[NBO], const float* __restrict__ wseg, int lane) {
-  load_w<NBO, NBT>(wa, reinterpret_cast<const float4*>(wseg) + lane, 0);
+  load_w<NBO, NBT>(wa, wbuf_make(wseg, lane), 0);
 }
 
 template <int NBO, int NBT = NBO>
 __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ wseg,
                                           const float4* xl, int n_it, int lane) {
-  const float4* __restrict__ wp = reinterpret_cast<const float4*>(wseg) + lane;
+  const WBuf wp = wbuf_make(wseg, lane);
   float4 wb[NBO];
   float4 ba, bb;
   ba = xl[0];
@@ -238,11 +263,14 @@ __device__ __forceinline__ BSplit split8(const float4 lo, const float4 hi) {
 }
 
 template <int NH, int NSPLIT>
-__device__ __forceinline__ void load_w16(bf16x8 (&w)[NH][3], const bf16x8* __restrict__ wp, int kk, int nbo, int nb0) {
+__device__ __forceinline__ void load_w16(bf16x8 (&w)[NH][3], const WBuf& wp, int kk, int nbo, int nb0) {
 #pragma unroll
   for (int t = 0; t < NH; ++t)
 #pragma unroll
-    for (int sp = 0; sp < NSPLIT; ++sp) w[t][sp] = wp[((kk * nbo + nb0 + t) * 3 + sp) * 64];
+    for (int sp = 0; sp < NSPLIT; ++sp) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.voff, (unsigned)(((kk * nbo + nb0 + t) * 3 + sp) * 1024), 0);
+      w[t][sp] = __builtin_bit_cast(bf16x8, v);
+    }
 }
 
 template <int NBO, int NH, int NB0, int NSPLIT>
@@ -269,7 +297,7 @@ __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NBO], const float* __res
                                           int n_k16, int lane) {
   constexpr int H0 = (NBO + 1) / 2, H1 = NBO - H0;
   constexpr int PER = (NSPLIT == 3 ? 6 : (NSPLIT == 2 ? 3 : 1));  // MFMAs per output block and K step
-  const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(wseg) + lane;
+  const WBuf wp = wbuf_make(wseg, lane);
   bf16x8 wa[H0][3], wb[H1 > 0 ? H1 : 1][3];
   load_w16<H0, NSPLIT>(wa, wp, 0, NBO, 0);
   BSplit bc = split8<NSPLIT>(xl[0], xl[64]);
@@ -394,11 +422,21 @@ __device__ __forceinline__ void put4_pat(float* save, int nb, int q, int ld, con
 // packed into NBO/2 words (rsn_field_saved.relu_bits).  The dX sweeps mask by these bits instead of re-reading the
 // saved fp32 activations (1 KiB per point and layer -> 32 B; 124 fewer live registers in the sweeps).
 __device__ __forceinline__ unsigned relu_bits16(const f32x16& a) {
+  // pre-activation x > 0  <=>  its bit pattern, as an int, > 0: v_med3_i32(t, 0, 1), then v_lshl_or_b32.  Written as
+  // (non-volatile) asm: hipcc turns the C form into v_cmp_lt_i32 (SGPR pair) + a hazard nop + v_cndmask + v_or3.
   unsigned b = 0u;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int t = (int)__float_as_uint(a[r]);          // pre-activation x > 0  <=>  its bit pattern, as an int, > 0
-    b |= (unsigned)min(max(t, 0), 1) << r;               // v_med3_i32 + v_lshl_or_b32
+    const int t = (int)__float_as_uint(a[r]);
+    int bit;
+    if (r == 0) {
+      asm("v_med3_i32 %0, %1, 0, 1" : "=v"(bit) : "v"(t));
+      b = (unsigned)bit;
+    } else {
+      unsigned nb;
+      asm("v_med3_i32 %0, %2, 0, 1\n\tv_lshl_or_b32 %1, %0, %3, %4" : "=&v"(bit), "=v"(nb) : "v"(t), "n"(r), "v"(b));
+      b = nb;
+    }
   }
   return b;
 }
