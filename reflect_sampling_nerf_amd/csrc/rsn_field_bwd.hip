@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
   __shared__ float4 smem[4 * WAVE_F4];
 
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // a SCALAR (tile bases, buffer descriptors)
   float4* X = smem + wid * WAVE_F4 + lane;  // its XITS.. spill into the SH region (contiguous): NB*4+4 <= XITS+5
   float* Xf = reinterpret_cast<float*>(X);
 
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
     const long long p = p0 + m;
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
+    const int rows = (int)(n_points - p0 < 32 ? n_points - p0 : 32);  // valid rows of this wave's tile (wave-uniform)
     const float live = valid ? 1.0f : 0.0f;  // padded lanes contribute zero gradients
 
     auto bits_at = [&](int l) -> const unsigned* {  // rsn_field_saved.relu_bits: [L+1][N][2][NB/2] words
@@ -202,14 +203,14 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       f32x16 acc[4];
       zero_acc<4>(acc);
       gemm_mode<MODE, 4>(acc, pk + P.L.wT_rgb, pk + P.L.hT_rgb, X, 4, ln);
-      store_masked_bits<4, SBF>(acc, X, mb, h, (valid && a.gout.da_mid) ? row_ptr<SBF>(a.gout.da_mid, pc * 128) : nullptr);
+      store_masked_bits<4, SBF>(acc, X, mb, h, rowbuf<SBF>(a.gout.da_mid, p0 * 128, rows, 128, m, h));
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + P.L.wT_mid_x, pk + P.L.hT_mid_x, X, 16, ln);
-      store_act<NB, NB, false, SBF>(acc, X, (valid && a.gout.d_bott) ? row_ptr<SBF>(a.gout.d_bott, pc * W) : nullptr, h);
+      store_act<NB, NB, false, SBF>(acc, X, rowbuf<SBF>(a.gout.d_bott, p0 * W, rows, W, m, h), h);
     }
     // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
     {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + P.L.wT_bh, pk + P.L.hT_bh, X, NB * 4 + 4, ln);
-      store_masked_bits<NB, SBF>(acc, X, mb, h, valid ? row_ptr<SBF>(a.gout.dy, (long long)l * a.act_stride + pc * W) : nullptr);
+      store_masked_bits<NB, SBF>(acc, X, mb, h, rowbuf<SBF>(a.gout.dy, (long long)l * a.act_stride + p0 * W, rows, W, m, h));
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
     f32x16 eacc[4];
@@ -291,9 +292,9 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       zero_acc<NB>(acc);
       gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln);
 #ifdef RSN_BWD_NO_DYSTORE  // timing diagnostic (RSN_DIAG_BUILD only, tools/train_diag.sh): wrong results
-      store_masked_bits<NB, SBF>(acc, X, mb, h, nullptr);
+      store_masked_bits<NB, SBF>(acc, X, mb, h);
 #else
-      store_masked_bits<NB, SBF>(acc, X, mb, h, valid ? row_ptr<SBF>(a.gout.dy, (long long)(l - 1) * a.act_stride + pc * W) : nullptr);
+      store_masked_bits<NB, SBF>(acc, X, mb, h, rowbuf<SBF>(a.gout.dy, (long long)(l - 1) * a.act_stride + p0 * W, rows, W, m, h));
 #endif
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------

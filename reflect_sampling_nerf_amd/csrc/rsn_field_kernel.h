@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
   __shared__ float4 smem[4 * WAVE_F4];
 
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // a SCALAR: tile bases / buffer descriptors derive from it
   float4* X = smem + wid * WAVE_F4 + lane;
   float4* AUX = X + XITS * 64;
   float* Xf = reinterpret_cast<float*>(X);
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
     const long long p = p0 + m;
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
+    const int rows = (int)(n_points - p0 < 32 ? n_points - p0 : 32);  // valid rows of this wave's tile (wave-uniform)
     // training: this lane's slot in the ReLU bit masks of layer l (rsn_field_saved.relu_bits: [L+1][N][2][NB/2] words)
     auto bits_at = [&](int l) -> unsigned* {
       return a.saved.relu_bits + ((((long long)l * (a.act_stride / W)) + pc) * 2 + h) * (NB / 2 > 2 ? NB / 2 : 2);
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       for (int l = 1; l < P.num_layers; ++l) {
         pre_mode<MODE, NB>(wpre, pk + P.L.w_x[l], ln);
         // ReLU between layers; the accumulators restart from layer l's bias
-        store_act_init<NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (l - 1) * a.act_stride + pc * W) : nullptr,
+        store_act_init<NB, true, SBF>(acc, X, rowbuf<SBF>(TRAIN ? a.saved.act : nullptr, (l - 1) * a.act_stride + p0 * W, rows, W, m, h),
                                  h, pk + P.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
         RSN_T(3);
         gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_x[l], pk + P.L.h_x[l], X, NB * 4, ln);
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       }
       // out_activation = ReLU
       pre_mode<MODE, NB + 1>(wbh, pk + P.L.w_bh, ln);
-      store_act<NB, NB, true, SBF>(acc, X, (TRAIN && a.saved.act && valid) ? row_ptr<SBF>(a.saved.act, (P.num_layers - 1) * a.act_stride + pc * W) : nullptr, h,
+      store_act<NB, NB, true, SBF>(acc, X, rowbuf<SBF>(TRAIN ? a.saved.act : nullptr, (P.num_layers - 1) * a.act_stride + p0 * W, rows, W, m, h), h,
                               (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers - 1) : nullptr);
       RSN_T(3);
     }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
         *reinterpret_cast<float4*>(a.saved.heads + pc * 8) = make_float4(r1, r2, r3, r4);
       }
       // bottleneck output (no activation) becomes the x-part of mlp_mid's input
-      store_act<NB + 1, NB, false, SBF>(acc, X, (TRAIN && a.saved.bott && valid) ? row_ptr<SBF>(a.saved.bott, pc * W) : nullptr, h);
+      store_act<NB + 1, NB, false, SBF>(acc, X, rowbuf<SBF>(TRAIN ? a.saved.bott : nullptr, p0 * W, rows, W, m, h), h);
     }
 
     // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       gemm_mode_run<MODE, 4>(accm, wmx, pk + P.L.w_mid_x, pk + P.L.h_mid_x, X, NB * 4, ln);
       RSN_T(8);
       pre_mode<MODE, 1>(wrgb, pk + P.L.w_rgb, ln);
-      store_act<4, 4, true, SBF>(accm, X, (TRAIN && a.saved.hid && valid) ? row_ptr<SBF>(a.saved.hid, pc * 128) : nullptr, h,
+      store_act<4, 4, true, SBF>(accm, X, rowbuf<SBF>(TRAIN ? a.saved.hid : nullptr, p0 * 128, rows, 128, m, h), h,
                             (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers) : nullptr);
       RSN_T(3);
     }

@@ -382,41 +382,50 @@ template <bool SBF>
 __device__ __forceinline__ void put4(float* save, int off, const float4 v) {
   if (SBF) {
     const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-#ifdef RSN_NT_STORES
-    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(save) + off));
-#else
     *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(save) + off) = o;
-#endif
   } else {
-#ifdef RSN_NT_STORES
-    typedef float f32x4v __attribute__((ext_vector_type(4)));
-    const f32x4v o = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(o, reinterpret_cast<f32x4v*>(save + off));
-#else
     *reinterpret_cast<float4*>(save + off) = v;
-#endif
   }
 }
 
-#ifdef RSN_DIAG_STORE_PATTERN
-// DIAGNOSTIC (wrong data placement, same bytes): what the saved-row stores would cost with other address patterns.
-// The product pattern writes, per instruction, 32 rows x 32 B.  1: 8 rows x one full 128-B line (8 consecutive lanes per
-// row).  2: 8 rows x 32 B per 16 lanes, the four 16-lane groups on the four 32-B quarters of the same 8 lines (what an
-// LDS read-back without bank conflicts could feed).  `ld` = row length in elements.
+// The same rows through BUFFER stores (the product kernels): the descriptor covers the tile's VALID rows of a row-major
+// [N, row_elems] buffer (base = the tile's first row, wave-uniform), the lane sends one 32-bit offset (its row + 16 h
+// bytes) and the (block, q) position is a scalar offset.  Lanes past the last valid row fall outside the descriptor's
+// range and the hardware drops their stores: no per-lane null pointers, no exec-masked branches around the stores.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct RowBuf {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;
+  bool on;
+};
 template <bool SBF>
-__device__ __forceinline__ void put4_pat(float* save, int nb, int q, int ld, const float4 v) {
-  const int L = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-#if RSN_DIAG_STORE_PATTERN == 1
-  const int pr = 8 * q + (L >> 3), c = L & 7;
-#else
-  const int pr = 8 * q + (L & 7), c = 2 * (L >> 4) + ((L >> 3) & 1);
-#endif
-  put4<SBF>(save, (pr - (L & 31)) * ld + nb * 32 + 4 * c, v);
+__device__ __forceinline__ RowBuf rowbuf(float* base, long long elem, int rows, int row_elems, int m, int h) {
+  constexpr int BPE = SBF ? 2 : 4;
+  RowBuf b;
+  // a literal nullptr (eval instantiations) removes the stores at compile time; a buffer that is absent at run time gets
+  // an empty range instead of a branch around every store
+  b.on = !(__builtin_constant_p(base == nullptr) && base == nullptr);
+  b.r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(base) + elem * BPE, 0,
+                                          base != nullptr ? rows * row_elems * BPE : 0, 0x00020000);
+  b.voff = (unsigned)((m * row_elems + 4 * h) * BPE);
+  return b;
 }
-#define RSN_PUT4(SBF, save, nb, q, h, ld, v) put4_pat<SBF>(save, nb, q, ld, v)
-#else
-#define RSN_PUT4(SBF, save, nb, q, h, ld, v) put4<SBF>(save, ((nb) * 4 + (q)) * 8 + 4 * (h), v)
-#endif
+__device__ __forceinline__ bool sv_on(const float* s) { return s != nullptr; }
+__device__ __forceinline__ bool sv_on(const RowBuf& b) { return b.on; }
+template <bool SBF>
+__device__ __forceinline__ void sv_put(float* save, int nb, int q, int h, const float4 v) {
+  put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
+}
+template <bool SBF>
+__device__ __forceinline__ void sv_put(const RowBuf& b, int nb, int q, int, const float4 v) {
+  if (SBF) {
+    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), b.r, b.voff, (nb * 4 + q) * 16, 0);
+  } else {
+    const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (nb * 4 + q) * 32, 0);
+  }
+}
 
 // ReLU sign bits of one lane: bit nb*16 + r = (accumulator register r of block nb, the layer's pre-activation) > 0,
 // packed into NBO/2 words (rsn_field_saved.relu_bits).  The dX sweeps mask by these bits instead of re-reading the
@@ -491,9 +500,9 @@ __device__ __forceinline__ unsigned bit_mask(int word, int pos) {
 
 // dX-sweep epilogue on mask bits: X[it][lane] = bit ? acc : 0 (v_bfe_i32 gives 0 / -1, one v_and applies it);
 // optionally also stored to row `save` (backward pass: the layer's pre-activation gradient for the weight gradients)
-template <int NBO, bool SBF = false>
+template <int NBO, bool SBF = false, class SV = float*>
 __device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], float4* xl, const ReluBits<NBO>& m, int h,
-                                                  float* save = nullptr) {
+                                                  SV save = nullptr) {
 #pragma unroll
   for (int nb = 0; nb < NBO; ++nb)
 #pragma unroll
@@ -506,15 +515,15 @@ __device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], floa
       v.z = __uint_as_float(__float_as_uint(acc[nb][4 * q + 2]) & bit_mask(word, base + 2));
       v.w = __uint_as_float(__float_as_uint(acc[nb][4 * q + 3]) & bit_mask(word, base + 3));
       xl[(nb * 4 + q) * 64] = v;
-      if (save) RSN_PUT4(SBF, save, nb, q, h, NBO * 32, v);
+      if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
     }
 }
 
 // X[it = nb*4+q][lane] = act(acc[nb][4q..4q+3])   (bias already inside acc, see init_acc).
 // save (training): the same float4 also goes to row `save` of a row-major [N, 32*NBS] activation buffer
 // (this lane's point; the four q of one nb complete one 128-B line per row).
-template <int NBO, int NBS, bool RELU, bool SBF = false>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, float* save = nullptr, int h = 0,
+template <int NBO, int NBS, bool RELU, bool SBF = false, class SV = float*>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, SV save = nullptr, int h = 0,
                                           unsigned* bits = nullptr) {
   unsigned bw[NBS / 2 > 0 ? NBS / 2 : 1];
 #pragma unroll
@@ -533,7 +542,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
         v.w = relu_f(v.w);
       }
       xl[(nb * 4 + q) * 64] = v;
-      if (save) RSN_PUT4(SBF, save, nb, q, h, NBS * 32, v);
+      if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
     }
   }
   if (RELU && bits) {
@@ -550,8 +559,8 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
 
 // store_act of one layer fused with init_acc of the next (same NBO): block by block the accumulators are read out and
 // immediately re-loaded with the next layer's bias, so the bias round trip hides under the rest of the epilogue.
-template <int NBO, bool RELU, bool SBF = false>
-__device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, float* save, int h,
+template <int NBO, bool RELU, bool SBF = false, class SV = float*>
+__device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, SV save, int h,
                                                const float* __restrict__ bias, unsigned* bits = nullptr) {
   unsigned bw[NBO / 2 > 0 ? NBO / 2 : 1];
 #pragma unroll
@@ -570,7 +579,7 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, f
         v.w = relu_f(v.w);
       }
       xl[(nb * 4 + q) * 64] = v;
-      if (save) RSN_PUT4(SBF, save, nb, q, h, NBO * 32, v);
+      if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
       const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
       acc[nb][4 * q + 0] = bv.x;
       acc[nb][4 * q + 1] = bv.y;
