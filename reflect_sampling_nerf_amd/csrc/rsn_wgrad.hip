@@ -177,6 +177,64 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
       }
     }
   };
+  // The same rows through BUFFER loads (the main loop): per stage one scalar descriptor for dY and one for X (base = row m0
+  // of the segment, wave-uniform), the point of the stage and the float4 of the row in the scalar offset, and ONE 32-bit
+  // lane offset per operand (the lane's half h and its column), loop-invariant -- instead of a 64-bit address per load,
+  // rebuilt from the row index with v_mul / v_mad_u64 / v_lshl_add_u64 (57 VALU per stage pair).
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int DBPE = DB ? 2 : 4, XBPE = XB ? 2 : 4;
+  const int hrow = BF ? 8 * h : h;  // row of the stage this lane's point p is: hrow + prow(p)
+  auto prow = [&](int p) { return BF ? p : 2 * p; };
+  unsigned vd[2], vx[NKB];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) vd[t] = (unsigned)((hrow * a.ld_dy + cdy[t]) * DBPE);
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) vx[kb] = (unsigned)((hrow * a.ld_x + cx[kb]) * XBPE);
+  auto load_row_b = [&](int buf, int p, long long m0) {
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(dyp)) + m0 * a.ld_dy * DBPE, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(xp)) + m0 * a.ld_x * XBPE, 0, 0x7fffffff, 0x00020000);
+    const unsigned sd = (unsigned)(prow(p) * a.ld_dy * DBPE), sx = (unsigned)(prow(p) * a.ld_x * XBPE);
+    if constexpr (DB) {
+      ua[buf][p] = __builtin_amdgcn_raw_buffer_load_b32(rd, vd[0], sd, 0);
+    } else if constexpr (DV) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rd, vd[0], sd, 0);
+      fa[buf][p][0] = __uint_as_float(v.x);
+      fa[buf][p][1] = __uint_as_float(v.y);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fa[buf][p][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vd[t], sd, 0));
+    }
+    if constexpr (XB) {
+      if constexpr (NKB == 8) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, vx[0], sx, 0);
+        ub[buf][p][0] = v.x; ub[buf][p][1] = v.y; ub[buf][p][2] = v.z; ub[buf][p][3] = v.w;
+      } else if constexpr (NKB == 4) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, vx[0], sx, 0);
+        ub[buf][p][0] = v.x; ub[buf][p][1] = v.y;
+      } else {
+        ub[buf][p][0] = __builtin_amdgcn_raw_buffer_load_b32(rx, vx[0], sx, 0);
+      }
+    } else if constexpr (XV && NKB >= 4) {
+#pragma unroll
+      for (int q = 0; q < NKB / 4; ++q) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, vx[0], sx + 16u * q, 0);
+        fb[buf][p][4 * q + 0] = __uint_as_float(v.x);
+        fb[buf][p][4 * q + 1] = __uint_as_float(v.y);
+        fb[buf][p][4 * q + 2] = __uint_as_float(v.z);
+        fb[buf][p][4 * q + 3] = __uint_as_float(v.w);
+      }
+    } else if constexpr (XV) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, vx[0], sx, 0);
+      fb[buf][p][0] = __uint_as_float(v.x);
+      fb[buf][p][1] = __uint_as_float(v.y);
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) fb[buf][p][kb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[kb], sx, 0));
+    }
+  };
   auto mma_stage = [&](int buf) {
     if constexpr (BF == 3) {
       bf16x8 a1[2], a2[2], a3[2];
@@ -314,7 +372,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
       const long long tc = t < cnt ? t : cnt - 1;
       const long long m0 = (first + tc * G) * step;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) load_row(buf, p, m0 + roff(p), true);
+      for (int p = 0; p < NP; ++p) load_row_b(buf, p, m0);
     };
     if (cnt > 0) {
       any = true;
@@ -323,7 +381,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
         for (int b = 0; b < NBUF - 1; ++b) load_stage(b, b);
       } else {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) load_row(0, p, first * step + roff(p), true);
+        for (int p = 0; p < NP; ++p) load_row_b(0, p, first * step);
       }
     }
     long long j = 0;
@@ -359,13 +417,13 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
         // block between two MFMA bursts they left the matrix pipe idle for ~10 % of the loop.  Straight-line body
         // (the prefetch index is clamped, not branched on) so that the scheduler can interleave.
 #pragma unroll
-        for (int p = 0; p < NP; ++p) load_row(1, p, m0 + gs + roff(p), true);
+        for (int p = 0; p < NP; ++p) load_row_b(1, p, m0 + gs);
         mma_stage(0);
         interleave_stage();
         __builtin_amdgcn_sched_barrier(0);
         const long long m2 = (j + 2 < cnt) ? m0 + 2 * gs : m0 + gs;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) load_row(0, p, m2 + roff(p), true);
+        for (int p = 0; p < NP; ++p) load_row_b(0, p, m2);
         mma_stage(1);
         interleave_stage();
         __builtin_amdgcn_sched_barrier(0);
