@@ -116,10 +116,11 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     }
   }
 
-  // Stage buffers.  fp32 rows: 80 registers per stage, two fit beside the 256 accumulators (one stage = 512 MFMA cycles of
-  // cover for the next one's loads).  bf16 rows are 40 registers per stage: FOUR buffers, three stages (1536 MFMA cycles)
+  // Stage buffers.  Exact fp32 (8 points per stage, 40 registers): FOUR buffers, three stages (12,288 MFMA cycles) in flight
+  // -- possible since the buffer loads freed ~150 address registers; 12.75 -> 12.58 ms per step.  Split / plain bf16 over
+  // fp32 rows: 80 registers per stage, two fit beside the 256 accumulators (one stage = 512 MFMA cycles of cover).  bf16 rows are 40 registers per stage: FOUR buffers, three stages (1536 MFMA cycles)
   // in flight -- the plain-bf16 reduction is bound by load latency, not by bytes (profiles/r03_wgrad_rows.txt).
-  constexpr int NBUF = (DB && (XB || NKB <= 4)) ? 4 : 2;  // (fp32 X rows of <= 128 columns are <= 40 registers per stage too)
+  constexpr int NBUF = ((BF == 0 && XV) || (DB && (XB || NKB <= 4))) ? 4 : 2;  // (fp32 X rows of <= 128 columns are <= 40 registers per stage too)
   float fa[NBUF][DB ? 1 : NP][2], fb[NBUF][XB ? 1 : NP][NKB];  // [buffer][point of this lane][block]
   unsigned ua[NBUF][DB ? NP : 1], ub[NBUF][XB ? NP : 1][NKB / 2];  // bf16 rows: packed pairs (rows 2i, 2i+1 | columns 2w, 2w+1)
   auto roff = [&](int p) { return BF ? 8 * h + p : 2 * p + h; };  // row of the stage this lane's p-th point is
@@ -234,6 +235,11 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) fb[buf][p][kb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[kb], sx, 0));
     }
+  };
+  // the split-bf16 variant (BF = 3) keeps the pointer loads: with buffer loads its loop ran 5 % slower (10.8 against 10.25 ms
+  // per step; its conversion VALU fills the issue slots the address arithmetic used to share)
+  auto load_row_m = [&](int buf, int p, long long m0) {
+    if constexpr (BF == 3) load_row(buf, p, m0 + roff(p), true); else load_row_b(buf, p, m0);
   };
   auto mma_stage = [&](int buf) {
     if constexpr (BF == 3) {
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
       const long long tc = t < cnt ? t : cnt - 1;
       const long long m0 = (first + tc * G) * step;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) load_row_b(buf, p, m0);
+      for (int p = 0; p < NP; ++p) load_row_m(buf, p, m0);
     };
     if (cnt > 0) {
       any = true;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
         for (int b = 0; b < NBUF - 1; ++b) load_stage(b, b);
       } else {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) load_row_b(0, p, first * step);
+        for (int p = 0; p < NP; ++p) load_row_m(0, p, first * step);
       }
     }
     long long j = 0;
@@ -417,13 +423,13 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
         // block between two MFMA bursts they left the matrix pipe idle for ~10 % of the loop.  Straight-line body
         // (the prefetch index is clamped, not branched on) so that the scheduler can interleave.
 #pragma unroll
-        for (int p = 0; p < NP; ++p) load_row_b(1, p, m0 + gs);
+        for (int p = 0; p < NP; ++p) load_row_m(1, p, m0 + gs);
         mma_stage(0);
         interleave_stage();
         __builtin_amdgcn_sched_barrier(0);
         const long long m2 = (j + 2 < cnt) ? m0 + 2 * gs : m0 + gs;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) load_row_b(0, p, m2);
+        for (int p = 0; p < NP; ++p) load_row_m(0, p, m2);
         mma_stage(1);
         interleave_stage();
         __builtin_amdgcn_sched_barrier(0);
