@@ -7,7 +7,7 @@
 #include "rsn.h"
 
 // Diagnostic builds.  Timing ablations that give WRONG RESULTS BY CONSTRUCTION (RSN_RING_NO_*, RSN_RING_MFMA16,
-// RSN_R16_*, RSN_BWD_NO_DYSTORE), the per-phase cycle counters (RSN_PHASE_TIMERS) and any other -D experiment exist
+// RSN_R16_*, RSN_DIAG_NO_SAVED_ROWS), the per-phase cycle counters (RSN_PHASE_TIMERS) and any other -D experiment exist
 // only in libraries built with -DRSN_DIAG_BUILD, which tools/_variant.py adds and _build.py's product flags never
 // contain; rsn_abi_version() of such a library carries RSN_ABI_DIAG_FLAG, and the Python loader refuses it as the
 // product library (reflect_sampling_nerf_amd/_abi.py).
@@ -15,7 +15,8 @@
 #ifndef RSN_DIAG_BUILD
 #if defined(RSN_RING_NO_BARRIER) || defined(RSN_RING_NO_WAIT) || defined(RSN_RING_NO_DMA) || defined(RSN_RING_NO_MFMA) || \
     defined(RSN_RING_MFMA16) || defined(RSN_RING_NO_ENCODE) || defined(RSN_RING_SETPRIO) || defined(RSN_R16_NO_LDS_READ) || \
-    defined(RSN_R16_NO_MFMA) || defined(RSN_R16_DOUBLE_MFMA) || defined(RSN_BWD_NO_DYSTORE) || defined(RSN_PHASE_TIMERS)
+    defined(RSN_R16_NO_MFMA) || defined(RSN_R16_DOUBLE_MFMA) || defined(RSN_PHASE_TIMERS) || \
+    defined(RSN_DIAG_NO_SAVED_ROWS)
 #error "timing-diagnostic macros need -DRSN_DIAG_BUILD (tools/_variant.py): they never go into librsn_hip.so"
 #endif
 #endif

@@ -165,6 +165,16 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
     const int rows = (int)(n_points - p0 < 32 ? n_points - p0 : 32);  // valid rows of this wave's tile (wave-uniform)
+    // Layer-gradient rows kept for the weight gradients leave from the epilogue that produces them.  (The forward kernel's
+    // exact-fp32 GEMMs store the rows they READ from inside the K loop, gemm_run's `save`; the same arrangement here --
+    // LOOPST = (MODE == 0), parity green -- ran the sweeps 12.1 -> 12.5 ms per step on the same box, so it stays off.)
+    constexpr bool LOOPST = false;
+    auto rb_epi = [&](float* base, long long elem, int row_elems) {
+      return rowbuf<SBF>(LOOPST ? nullptr : base, elem, rows, row_elems, m, h);
+    };
+    auto rb_loop = [&](float* base, long long elem, int row_elems) {
+      return rowbuf<false>(LOOPST ? base : nullptr, elem, rows, row_elems, m, h);
+    };
     const float live = valid ? 1.0f : 0.0f;  // padded lanes contribute zero gradients
 
     auto bits_at = [&](int l) -> const unsigned* {  // rsn_field_saved.relu_bits: [L+1][N][2][NB/2] words
@@ -203,14 +213,14 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       f32x16 acc[4];
       zero_acc<4>(acc);
       gemm_mode<MODE, 4>(acc, pk + P.L.wT_rgb, pk + P.L.hT_rgb, X, 4, ln);
-      store_masked_bits<4, SBF>(acc, X, mb, h, rowbuf<SBF>(a.gout.da_mid, p0 * 128, rows, 128, m, h));
+      store_masked_bits<4, SBF>(acc, X, mb, h, rb_epi(a.gout.da_mid, p0 * 128, 128));
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + P.L.wT_mid_x, pk + P.L.hT_mid_x, X, 16, ln);
-      store_act<NB, NB, false, SBF>(acc, X, rowbuf<SBF>(a.gout.d_bott, p0 * W, rows, W, m, h), h);
+      gemm_mode<MODE, NB>(acc, pk + P.L.wT_mid_x, pk + P.L.hT_mid_x, X, 16, ln, rb_loop(a.gout.da_mid, p0 * 128, 128));
+      store_act<NB, NB, false, SBF>(acc, X, rb_epi(a.gout.d_bott, p0 * W, W), h);
     }
     // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
     {
@@ -276,8 +286,8 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + P.L.wT_bh, pk + P.L.hT_bh, X, NB * 4 + 4, ln);
-      store_masked_bits<NB, SBF>(acc, X, mb, h, rowbuf<SBF>(a.gout.dy, (long long)l * a.act_stride + p0 * W, rows, W, m, h));
+      gemm_mode<MODE, NB>(acc, pk + P.L.wT_bh, pk + P.L.hT_bh, X, NB * 4 + 4, ln, rb_loop(a.gout.d_bott, p0 * W, W));
+      store_masked_bits<NB, SBF>(acc, X, mb, h, rb_epi(a.gout.dy, (long long)l * a.act_stride + p0 * W, W));
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
     f32x16 eacc[4];
@@ -290,16 +300,18 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln);
-#ifdef RSN_BWD_NO_DYSTORE  // timing diagnostic (RSN_DIAG_BUILD only, tools/train_diag.sh): wrong results
-      store_masked_bits<NB, SBF>(acc, X, mb, h);
-#else
-      store_masked_bits<NB, SBF>(acc, X, mb, h, rowbuf<SBF>(a.gout.dy, (long long)(l - 1) * a.act_stride + p0 * W, rows, W, m, h));
-#endif
+      gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln,
+                          rb_loop(a.gout.dy, (long long)l * a.act_stride + p0 * W, W));  // reads (and keeps) dy[l]
+      store_masked_bits<NB, SBF>(acc, X, mb, h, rb_epi(a.gout.dy, (long long)(l - 1) * a.act_stride + p0 * W, W));
+    }
+    if (LOOPST && !a.need_input_grad) {  // dy[0] has no GEMM behind it on this path: its rows leave here
+      const RowBuf r0 = rb_loop(a.gout.dy, p0 * W, W);
+#pragma unroll 4
+      for (int it = 0; it < NB * 4; ++it) sv_put_it(r0, it, X[it * 64]);
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
     if (a.need_input_grad) {
-      gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln);
+      gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln, rb_loop(a.gout.dy, p0 * W, W));  // keeps dy[0]
       store_act<4, 4, false>(eacc, X);  // d loss / d encoded input, slot order
       const float* encp = a.saved.enc + pc * RSN_K_ENC_PAD;
       float dvar[3];

@@ -82,6 +82,15 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
     const int rows = (int)(n_points - p0 < 32 ? n_points - p0 : 32);  // valid rows of this wave's tile (wave-uniform)
+    // Saved rows (training).  Exact fp32: a row leaves from the K loop of the GEMM that READS it (one store per
+    // K-iteration, gemm_run); the split / plain bf16 loops store from the epilogue that produces it.
+    constexpr bool LOOPST = TRAIN && MODE == 0;
+    auto rb_epi = [&](float* base, long long elem, int row_elems) {
+      return rowbuf<SBF>((TRAIN && !LOOPST) ? base : nullptr, elem, rows, row_elems, m, h);
+    };
+    auto rb_loop = [&](float* base, long long elem, int row_elems) {
+      return rowbuf<false>(LOOPST ? base : nullptr, elem, rows, row_elems, m, h);
+    };
     // training: this lane's slot in the ReLU bit masks of layer l (rsn_field_saved.relu_bits: [L+1][N][2][NB/2] words)
     auto bits_at = [&](int l) -> unsigned* {
       return a.saved.relu_bits + ((((long long)l * (a.act_stride / W)) + pc) * 2 + h) * (NB / 2 > 2 ? NB / 2 : 2);
@@ -193,10 +202,11 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       for (int l = 1; l < P.num_layers; ++l) {
         pre_mode<MODE, NB>(wpre, pk + P.L.w_x[l], ln);
         // ReLU between layers; the accumulators restart from layer l's bias
-        store_act_init<NB, true, SBF>(acc, X, rowbuf<SBF>(TRAIN ? a.saved.act : nullptr, (l - 1) * a.act_stride + p0 * W, rows, W, m, h),
+        store_act_init<NB, true, SBF>(acc, X, rb_epi(a.saved.act, (l - 1) * a.act_stride + p0 * W, W),
                                  h, pk + P.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
         RSN_T(3);
-        gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_x[l], pk + P.L.h_x[l], X, NB * 4, ln);
+        gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_x[l], pk + P.L.h_x[l], X, NB * 4, ln,
+                                rb_loop(a.saved.act, (l - 1) * a.act_stride + p0 * W, W));
         RSN_T(4);
         if (l == P.skip_layer) {
           pre_mode<MODE, NB>(wpre, pk + P.L.w_enc_skip, ln);
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       }
       // out_activation = ReLU
       pre_mode<MODE, NB + 1>(wbh, pk + P.L.w_bh, ln);
-      store_act<NB, NB, true, SBF>(acc, X, rowbuf<SBF>(TRAIN ? a.saved.act : nullptr, (P.num_layers - 1) * a.act_stride + p0 * W, rows, W, m, h), h,
+      store_act<NB, NB, true, SBF>(acc, X, rb_epi(a.saved.act, (P.num_layers - 1) * a.act_stride + p0 * W, W), h,
                               (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers - 1) : nullptr);
       RSN_T(3);
     }
@@ -232,7 +242,8 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       f32x16 acc[NB + 1];
       init_acc<NB + 1>(acc, pk + P.L.b_bh, h);
       RSN_T(1);
-      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + P.L.w_bh, pk + P.L.h_bh, X, NB * 4, ln);
+      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + P.L.w_bh, pk + P.L.h_bh, X, NB * 4, ln,
+                                  rb_loop(a.mode == RSN_MODE_EMB ? nullptr : a.saved.act, (P.num_layers - 1) * a.act_stride + p0 * W, W));
       RSN_T(5);
       pre_mode<MODE, 4>(wmid, pk + P.L.w_mid_sh, ln);
       const float r0 = acc[NB][0], r1 = acc[NB][1], r2 = acc[NB][2], r3 = acc[NB][3];
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
         *reinterpret_cast<float4*>(a.saved.heads + pc * 8) = make_float4(r1, r2, r3, r4);
       }
       // bottleneck output (no activation) becomes the x-part of mlp_mid's input
-      store_act<NB + 1, NB, false, SBF>(acc, X, rowbuf<SBF>(TRAIN ? a.saved.bott : nullptr, p0 * W, rows, W, m, h), h);
+      store_act<NB + 1, NB, false, SBF>(acc, X, rb_epi(a.saved.bott, p0 * W, W), h);
     }
 
     // ---------------- SH-34 of the view direction, attenuated by softplus roughness -----------------
@@ -311,10 +322,10 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       pre_mode<MODE, 4>(wmx, pk + P.L.w_mid_x, ln);
       gemm_mode_run<MODE, 4>(accm, wmid, pk + P.L.w_mid_sh, pk + P.L.h_mid_sh, AUX, RSN_SH_ITS, ln);
       RSN_T(7);
-      gemm_mode_run<MODE, 4>(accm, wmx, pk + P.L.w_mid_x, pk + P.L.h_mid_x, X, NB * 4, ln);
+      gemm_mode_run<MODE, 4>(accm, wmx, pk + P.L.w_mid_x, pk + P.L.h_mid_x, X, NB * 4, ln, rb_loop(a.saved.bott, p0 * W, W));
       RSN_T(8);
       pre_mode<MODE, 1>(wrgb, pk + P.L.w_rgb, ln);
-      store_act<4, 4, true, SBF>(accm, X, rowbuf<SBF>(TRAIN ? a.saved.hid : nullptr, p0 * 128, rows, 128, m, h), h,
+      store_act<4, 4, true, SBF>(accm, X, rb_epi(a.saved.hid, p0 * 128, 128), h,
                             (TRAIN && a.saved.relu_bits && valid) ? bits_at(P.num_layers) : nullptr);
       RSN_T(3);
     }
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       f32x16 accr[1];
       init_acc<1>(accr, pk + P.L.b_rgb, h);
       RSN_T(1);
-      gemm_mode_run<MODE, 1>(accr, wrgb, pk + P.L.w_rgb, pk + P.L.h_rgb, X, 16, ln);
+      gemm_mode_run<MODE, 1>(accr, wrgb, pk + P.L.w_rgb, pk + P.L.h_rgb, X, 16, ln, rb_loop(a.saved.hid, p0 * 128, 128));
       RSN_T(9);
       if (h == 1 && valid) {
         const float m0 = sigmoid_f(accr[0][0]);

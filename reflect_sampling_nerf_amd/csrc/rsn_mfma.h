@@ -106,6 +106,76 @@ __device__ __forceinline__ float relu_f(float x) {
   return y;
 }
 
+// Rows kept for the backward pass / the weight gradients.  fp32 rows in the exact and the split-bf16 modes; in the
+// reduced-precision training mode (RSN_MMA_BF16: the GEMMs round these values to bf16 anyway) the wide buffers
+// (activations, bottleneck, mid hidden; layer gradients) are stored AS bf16 -- half the step's HBM stream.  `save`
+// stays a float* in the signatures; SBF reinterprets it as a row of bf16 (element offsets, not bytes).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <bool SBF>
+__device__ __forceinline__ float* row_ptr(float* base, long long elem) {
+  return SBF ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(base) + elem) : base + elem;
+}
+template <bool SBF>
+__device__ __forceinline__ void put4(float* save, int off, const float4 v) {
+  if (SBF) {
+    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(save) + off) = o;
+  } else {
+    *reinterpret_cast<float4*>(save + off) = v;
+  }
+}
+
+// The same rows through BUFFER stores (the product kernels): the descriptor covers the tile's VALID rows of a row-major
+// [N, row_elems] buffer (base = the tile's first row, wave-uniform), the lane sends one 32-bit offset (its row + 16 h
+// bytes) and the (block, q) position is a scalar offset.  Lanes past the last valid row fall outside the descriptor's
+// range and the hardware drops their stores: no per-lane null pointers, no exec-masked branches around the stores.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct RowBuf {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;
+  unsigned lim;  // bytes of one row (sv_put_it: K-iterations past the row are not stored)
+  bool on;
+};
+template <bool SBF>
+__device__ __forceinline__ RowBuf rowbuf(float* base, long long elem, int rows, int row_elems, int m, int h) {
+  constexpr int BPE = SBF ? 2 : 4;
+  RowBuf b;
+  // a literal nullptr (eval instantiations) removes the stores at compile time; a buffer that is absent at run time gets
+  // an empty range instead of a branch around every store
+  b.on = !(__builtin_constant_p(base == nullptr) && base == nullptr);
+#ifdef RSN_DIAG_NO_SAVED_ROWS  // timing ablation (wrong training results): no saved-row store is issued
+  b.on = false;
+#endif
+  b.r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(base) + elem * BPE, 0,
+                                          base != nullptr ? rows * row_elems * BPE : 0, 0x00020000);
+  b.voff = (unsigned)((m * row_elems + 4 * h) * BPE);
+  b.lim = (unsigned)(row_elems * BPE);
+  return b;
+}
+__device__ __forceinline__ bool sv_on(const float* s) { return s != nullptr; }
+__device__ __forceinline__ bool sv_on(const RowBuf& b) { return b.on; }
+template <bool SBF>
+__device__ __forceinline__ void sv_put(float* save, int nb, int q, int h, const float4 v) {
+  put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
+}
+template <bool SBF>
+__device__ __forceinline__ void sv_put(const RowBuf& b, int nb, int q, int, const float4 v) {
+  if (SBF) {
+    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), b.r, b.voff, (nb * 4 + q) * 16, 0);
+  } else {
+    const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (nb * 4 + q) * 32, 0);
+  }
+}
+// the float4 of K-iteration `it` of the lane's row (features it*8 + 4h ..): the same bytes sv_put(nb = it/4, q = it%4) writes
+__device__ __forceinline__ void sv_put_it(const float*, int, const float4) {}
+__device__ __forceinline__ void sv_put_it(const RowBuf& b, int it, const float4 v) {
+  const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  if ((unsigned)it * 32u < b.lim) __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (unsigned)it * 32u, 0);  // wave-uniform
+}
+
 // ------------------------------------------------------------------------------------------------
 // MFMA K loop: acc[nb] += W_seg[nb-block] * X, weights double-buffered in registers.
 // ------------------------------------------------------------------------------------------------
@@ -117,7 +187,6 @@ __device__ __forceinline__ float relu_f(float x) {
 // "per-load cost" of rounds 1-2: with buffer loads the eval kernel went 4.90 -> 4.63 ms (83.8 -> 88.6 % of the fp32-MFMA
 // peak) and the training forward 22.5 -> 21.4 ms per step (76.6 -> 80.4 %), same box (profiles/r03_buffer_loads.txt).
 // Reads past the descriptor's 2 GiB window return 0 (never reached: a packed segment is < 1 MiB).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct WBuf {
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;  // lane * 16
@@ -176,9 +245,14 @@ __device__ __forceinline__ void pre_w(float4 (&wa)[NBO], const float* __restrict
   load_w<NBO, NBT>(wa, wbuf_make(wseg, lane), 0);
 }
 
-template <int NBO, int NBT = NBO>
+// `save` (optional): the rows of the activations this GEMM READS are kept for the backward pass (rsn_field_saved.act /
+// bott / hid; rsn_field_grads_out.dy ...).  The K loop holds float4 `it` of the lane's row in a register anyway (the
+// MFMA B operand), so the row leaves as ONE buffer store per K-iteration, 2,048 MFMA cycles apart -- instead of a burst
+// of 32 stores in the epilogue that produced it, which blocked the wave at the CU's 64 B/clk write port
+// (profiles/r03_store_in_loop.txt).
+template <int NBO, int NBT = NBO, class SV = const float*>
 __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ wseg,
-                                          const float4* xl, int n_it, int lane) {
+                                          const float4* xl, int n_it, int lane, SV save = nullptr) {
   const WBuf wp = wbuf_make(wseg, lane);
   float4 wb[NBO];
   float4 ba, bb;
@@ -189,6 +263,7 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], 
     load_w<NBO, NBT>(wb, wp, it + 1);
     bb = xl[(it + 1) * 64];
     mma4<NBO>(acc, wa, ba);
+    if (sv_on(save)) sv_put_it(save, it, ba);
     interleave_loads<NBO>();
     __builtin_amdgcn_sched_barrier(0);
     {  // unconditional prefetch with a clamped index: one control path => exact vmcnt counts
@@ -197,18 +272,22 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], 
       ba = xl[in * 64];
     }
     mma4<NBO>(acc, wb, bb);
+    if (sv_on(save)) sv_put_it(save, it + 1, bb);
     interleave_loads<NBO>();
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (it < n_it) mma4<NBO>(acc, wa, ba);
+  if (it < n_it) {
+    mma4<NBO>(acc, wa, ba);
+    if (sv_on(save)) sv_put_it(save, it, ba);
+  }
 }
 
-template <int NBO, int NBT = NBO>
+template <int NBO, int NBT = NBO, class SV = const float*>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl, int n_it,
-                                     int lane) {
+                                     int lane, SV save = nullptr) {
   float4 wa[NBO];
   pre_w<NBO, NBT>(wa, wseg, lane);
-  gemm_run<NBO, NBT>(acc, wa, wseg, xl, n_it, lane);
+  gemm_run<NBO, NBT>(acc, wa, wseg, xl, n_it, lane, save);
 }
 
 // acc[nb][4q+j] = bias[nb*32 + 8q + 4h + j]: the accumulators start from the bias (what torch's addmm does),
@@ -332,12 +411,12 @@ __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NBO], const float* __res
 }
 
 // dispatch on the MMA mode: MODE 0 = fp32 MFMA over n_it K-iterations of 8, else split-bf16 over ceil(n_it/2) K=16 steps
-template <int MODE, int NBO, int NBT = NBO>
+template <int MODE, int NBO, int NBT = NBO, class SV = const float*>
 __device__ __forceinline__ void gemm_mode(f32x16 (&acc)[NBO], const float* __restrict__ w32, const float* __restrict__ w16,
-                                          const float4* xl, int n_it, int lane) {
+                                          const float4* xl, int n_it, int lane, SV save = nullptr) {
   static_assert(MODE == 0 || NBT == NBO, "the split-bf16 loops own every output block of their segment");
   if (MODE == 0) {
-    gemm<NBO, NBT>(acc, w32, xl, n_it, lane);
+    gemm<NBO, NBT>(acc, w32, xl, n_it, lane, save);
   } else {
     gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
   }
@@ -350,12 +429,13 @@ __device__ __forceinline__ void pre_mode(float4 (&wa)[NBO], const float* __restr
   if (MODE == 0) pre_w<NBO, NBT>(wa, w32, lane);
 }
 
-template <int MODE, int NBO, int NBT = NBO>
+template <int MODE, int NBO, int NBT = NBO, class SV = const float*>
 __device__ __forceinline__ void gemm_mode_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ w32,
-                                              const float* __restrict__ w16, const float4* xl, int n_it, int lane) {
+                                              const float* __restrict__ w16, const float4* xl, int n_it, int lane,
+                                              SV save = nullptr) {
   static_assert(MODE == 0 || NBT == NBO, "the split-bf16 loops own every output block of their segment");
   if (MODE == 0) {
-    gemm_run<NBO, NBT>(acc, wa, w32, xl, n_it, lane);
+    gemm_run<NBO, NBT>(acc, wa, w32, xl, n_it, lane, save);  // (the split-bf16 loops take no saver: their epilogues store)
   } else {
     gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
   }
@@ -367,64 +447,6 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
   for (int nb = 0; nb < NBO; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
-}
-
-// Rows kept for the backward pass / the weight gradients.  fp32 rows in the exact and the split-bf16 modes; in the
-// reduced-precision training mode (RSN_MMA_BF16: the GEMMs round these values to bf16 anyway) the wide buffers
-// (activations, bottleneck, mid hidden; layer gradients) are stored AS bf16 -- half the step's HBM stream.  `save`
-// stays a float* in the signatures; SBF reinterprets it as a row of bf16 (element offsets, not bytes).
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-template <bool SBF>
-__device__ __forceinline__ float* row_ptr(float* base, long long elem) {
-  return SBF ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(base) + elem) : base + elem;
-}
-template <bool SBF>
-__device__ __forceinline__ void put4(float* save, int off, const float4 v) {
-  if (SBF) {
-    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(save) + off) = o;
-  } else {
-    *reinterpret_cast<float4*>(save + off) = v;
-  }
-}
-
-// The same rows through BUFFER stores (the product kernels): the descriptor covers the tile's VALID rows of a row-major
-// [N, row_elems] buffer (base = the tile's first row, wave-uniform), the lane sends one 32-bit offset (its row + 16 h
-// bytes) and the (block, q) position is a scalar offset.  Lanes past the last valid row fall outside the descriptor's
-// range and the hardware drops their stores: no per-lane null pointers, no exec-masked branches around the stores.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-struct RowBuf {
-  __amdgpu_buffer_rsrc_t r;
-  unsigned voff;
-  bool on;
-};
-template <bool SBF>
-__device__ __forceinline__ RowBuf rowbuf(float* base, long long elem, int rows, int row_elems, int m, int h) {
-  constexpr int BPE = SBF ? 2 : 4;
-  RowBuf b;
-  // a literal nullptr (eval instantiations) removes the stores at compile time; a buffer that is absent at run time gets
-  // an empty range instead of a branch around every store
-  b.on = !(__builtin_constant_p(base == nullptr) && base == nullptr);
-  b.r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(base) + elem * BPE, 0,
-                                          base != nullptr ? rows * row_elems * BPE : 0, 0x00020000);
-  b.voff = (unsigned)((m * row_elems + 4 * h) * BPE);
-  return b;
-}
-__device__ __forceinline__ bool sv_on(const float* s) { return s != nullptr; }
-__device__ __forceinline__ bool sv_on(const RowBuf& b) { return b.on; }
-template <bool SBF>
-__device__ __forceinline__ void sv_put(float* save, int nb, int q, int h, const float4 v) {
-  put4<SBF>(save, (nb * 4 + q) * 8 + 4 * h, v);
-}
-template <bool SBF>
-__device__ __forceinline__ void sv_put(const RowBuf& b, int nb, int q, int, const float4 v) {
-  if (SBF) {
-    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), b.r, b.voff, (nb * 4 + q) * 16, 0);
-  } else {
-    const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (nb * 4 + q) * 32, 0);
-  }
 }
 
 // ReLU sign bits of one lane: bit nb*16 + r = (accumulator register r of block nb, the layer's pre-activation) > 0,

@@ -151,7 +151,7 @@ def test_bench_flop_accounting_matches_survey():
 
 
 def test_diagnostic_macros_cannot_enter_the_product_library(tmp_path):
-    """Timing ablations (RSN_RING_NO_*, RSN_R16_*, RSN_BWD_NO_DYSTORE: wrong results by construction) compile only under
+    """Timing ablations (RSN_RING_NO_*, RSN_R16_*, RSN_DIAG_NO_SAVED_ROWS: wrong results by construction) compile only under
     -DRSN_DIAG_BUILD, which the product flags never carry, and a diagnostic library reports RSN_ABI_DIAG_FLAG in
     rsn_abi_version() (the loader refuses it at the product path)."""
     import shutil
