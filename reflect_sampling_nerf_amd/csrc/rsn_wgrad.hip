@@ -449,6 +449,9 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     vprefix += n_full + (rem > 0 ? 1 : 0);
   }
   if (!any) return;  // wave-uniform: nothing accumulated, nothing to flush
+#ifdef RSN_DIAG_WG_NO_FLUSH  // timing ablation (wrong results): what the atomic flush costs
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
 
   // flush: C/D layout col = lane&31 (input-column slot), row = (r&3) + 8*(r>>2) + 4*h (output-row slot).  The
   // wave-private LDS tile turns "lane i holds columns i*NKB+kb" back into "lane i holds column kb*32+i" so that one
@@ -462,19 +465,27 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
     cdst[kb] = -1;
     if (k < a.k_in) cdst[kb] = a.col_map ? a.col_map[k] : k;
   }
+  // buffer atomics: descriptor over the n_out live rows of dW, the row's wave-uniform part in the scalar offset, one
+  // loop-invariant 32-bit lane offset per column block (lane half -> row part, destination column); rows >= n_out and
+  // padded columns fall outside the descriptor's range / get an out-of-range offset and are dropped by the hardware
+  const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc(a.dw, 0, a.n_out * a.ld_dw * 4, 0x00020000);
+  unsigned vdw[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+    vdw[kb] = cdst[kb] >= 0 ? (unsigned)(((DV ? 8 : 4) * h * a.ld_dw + cdst[kb]) * 4) : 0x40000000u;  // far past the descriptor, no 32-bit wrap with the scalar row offset
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (t == 1 && !t1_live) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int slot = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int n = DV ? nb0 * 32 + 2 * slot + t : (nb0 + t) * 32 + slot;
+      const int slot0 = (r & 3) + 8 * (r >> 2);  // + 4 h: in vdw
+      const int n0 = DV ? nb0 * 32 + 2 * slot0 + t : (nb0 + t) * 32 + slot0;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) trw[XV ? i * NKB + kb : kb * 32 + i] = acc[t][kb][r];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         const float v = trw[kb * 32 + i];
-        if (cdst[kb] >= 0 && n < a.n_out) atomicAdd(&a.dw[(long long)n * a.ld_dw + cdst[kb]], v);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rdw, vdw[kb], (unsigned)(n0 * a.ld_dw * 4), 0);
       }
     }
     if (a.db) {
