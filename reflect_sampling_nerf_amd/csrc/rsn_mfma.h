@@ -184,7 +184,7 @@ __device__ __forceinline__ void sv_put_it(const RowBuf& b, int it, const float4 
 // Weight fragments arrive through BUFFER loads: the segment base lives in a scalar buffer descriptor, the K-iteration in
 // the scalar offset, and a lane sends ONE 32-bit offset (lane * 16 + nb KiB, loop-invariant registers) instead of a
 // 64-bit address that a v_add_co pair advances per load.  The 64-bit-address form (global_load_dwordx4 v[lo:hi]) was the
-// "per-load cost" of rounds 1-2: with buffer loads the eval kernel went 4.90 -> 4.63 ms (83.8 -> 88.6 % of the fp32-MFMA
+// unexplained per-load cost of rounds 1-2: with buffer loads the eval kernel went 4.90 -> 4.63 ms (83.8 -> 88.6 % of the fp32-MFMA
 // peak) and the training forward 22.5 -> 21.4 ms per step (76.6 -> 80.4 %), same box (profiles/r03_buffer_loads.txt).
 // Reads past the descriptor's 2 GiB window return 0 (never reached: a packed segment is < 1 MiB).
 struct WBuf {
@@ -222,11 +222,10 @@ __device__ __forceinline__ void mma4(f32x16 (&acc)[NBO], const float4 (&w)[NBO],
 // Software pipeline: the loads of K-iteration it+1 are issued while the 32 MFMAs of iteration it run, one load
 // after each of the first NBO MFMAs (sched_group_barrier pattern), so every load has a full iteration (2048 MFMA
 // cycles) of cover; hipcc on its own sinks the loads to just ahead of their first use.
-// Measured with tools/phase_report.py (BASELINE config 2): the trunk K loops run at 93.5 % of the MFMA issue rate;
-// with the weight stream removed they reach 98.8 %.  About half of that gap remains when every load hits L1, and
-// neither a prefetch distance of two iterations (three fragment buffers) nor the position of the loads inside the
-// iteration changes it: it is a per-load cost (register-file write traffic beside the MFMA operand reads, L2
-// service of the same lines to all CUs of an XCD), not exposed latency.
+// Measured with tools/phase_report.py (BASELINE config 2): with global_load_dwordx4 (64-bit VGPR addresses) the trunk K
+// loops ran at 93.5 % of the MFMA issue rate and neither the prefetch distance, the position of the loads nor L1 residency
+// changed that; with buffer loads (load_w above) they run at 98.4 % (profiles/r03_phase_eval.json): the cost was the
+// address path of the load, not its data or its latency.
 template <int NBO>
 __device__ __forceinline__ void interleave_loads() {
 #pragma unroll
