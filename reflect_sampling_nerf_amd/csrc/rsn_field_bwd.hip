@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
     const int rows = (int)(n_points - p0 < 32 ? n_points - p0 : 32);  // valid rows of this wave's tile (wave-uniform)
     // Layer-gradient rows kept for the weight gradients leave from the epilogue that produces them.  (The forward kernel's
     // exact-fp32 GEMMs store the rows they READ from inside the K loop, gemm_run's `save`; the same arrangement here --
-    // LOOPST = (MODE == 0), parity green -- ran the sweeps 12.1 -> 12.5 ms per step on the same box, so it stays off.)
+    // LOOPST = (MODE == 0), parity green -- ran the sweeps 12.1 -> 12.5 ms per step on the same box, 12.0 -> 12.3 ms with only the
+    // trunk's dy rows in-loop, so it stays off.)
     constexpr bool LOOPST = false;
     auto rb_epi = [&](float* base, long long elem, int row_elems) {
       return rowbuf<SBF>(LOOPST ? nullptr : base, elem, rows, row_elems, m, h);
