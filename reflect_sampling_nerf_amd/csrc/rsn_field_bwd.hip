@@ -213,14 +213,14 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[4];
       zero_acc<4>(acc);
-      gemm_mode<MODE, 4>(acc, pk + P.L.wT_rgb, pk + P.L.hT_rgb, X, 4, ln);
+      gemm_mode<MODE, 4, 4, true>(acc, pk + P.L.wT_rgb, pk + P.L.hT_rgb, X, 4, ln);
       store_masked_bits<4, SBF>(acc, X, mb, h, rb_epi(a.gout.da_mid, p0 * 128, 128));
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid -----------------
     {
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + P.L.wT_mid_x, pk + P.L.hT_mid_x, X, 16, ln, rb_loop(a.gout.da_mid, p0 * 128, 128));
+      gemm_mode<MODE, NB, NB, true>(acc, pk + P.L.wT_mid_x, pk + P.L.hT_mid_x, X, 16, ln, rb_loop(a.gout.da_mid, p0 * 128, 128));
       store_act<NB, NB, false, SBF>(acc, X, rb_epi(a.gout.d_bott, p0 * W, W), h);
     }
     // ---------------- stage 3: heads pre-activation gradients, then d emb = [W_b; W_heads]^T [d b; dz_heads] ------
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + P.L.wT_bh, pk + P.L.hT_bh, X, NB * 4 + 4, ln, rb_loop(a.gout.d_bott, p0 * W, W));
+      gemm_mode<MODE, NB, NB, true>(acc, pk + P.L.wT_bh, pk + P.L.hT_bh, X, NB * 4 + 4, ln, rb_loop(a.gout.d_bott, p0 * W, W));
       store_masked_bits<NB, SBF>(acc, X, mb, h, rb_epi(a.gout.dy, (long long)l * a.act_stride + p0 * W, W));
     }
     // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
@@ -296,12 +296,12 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
 #pragma unroll 1
     for (int l = P.num_layers - 1; l >= 1; --l) {
       if (a.need_input_grad && l == P.skip_layer)
-        gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc_skip, pk + P.L.hT_enc_skip, X, NB * 4, ln);
+        gemm_mode<MODE, 4, 4, true>(eacc, pk + P.L.wT_enc_skip, pk + P.L.hT_enc_skip, X, NB * 4, ln);
       const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l - 1));
       __builtin_amdgcn_sched_barrier(0);
       f32x16 acc[NB];
       zero_acc<NB>(acc);
-      gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln,
+      gemm_mode<MODE, NB, NB, true>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln,
                           rb_loop(a.gout.dy, (long long)l * a.act_stride + p0 * W, W));  // reads (and keeps) dy[l]
       store_masked_bits<NB, SBF>(acc, X, mb, h, rb_epi(a.gout.dy, (long long)(l - 1) * a.act_stride + p0 * W, W));
     }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
     }
     // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
     if (a.need_input_grad) {
-      gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln, rb_loop(a.gout.dy, p0 * W, W));  // keeps dy[0]
+      gemm_mode<MODE, 4, 4, true>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln, rb_loop(a.gout.dy, p0 * W, W));  // keeps dy[0]
       store_act<4, 4, false>(eacc, X);  // d loss / d encoded input, slot order
       const float* encp = a.saved.enc + pc * RSN_K_ENC_PAD;
       float dvar[3];

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       pre_mode<MODE, NB>(wpre, pk + P.L.w_enc0, ln);
       init_acc<NB>(acc, pk + P.L.b[0], h);
       RSN_T(1);
-      gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_enc0, pk + P.L.h_enc0, X, RSN_ENC_ITS, ln);
+      gemm_mode_run<MODE, NB, NB, TRAIN>(acc, wpre, pk + P.L.w_enc0, pk + P.L.h_enc0, X, RSN_ENC_ITS, ln);
       RSN_T(2);
 #pragma unroll 1
       for (int l = 1; l < P.num_layers; ++l) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
         store_act_init<NB, true, SBF>(acc, X, rb_epi(a.saved.act, (l - 1) * a.act_stride + p0 * W, W),
                                  h, pk + P.L.b[l], (TRAIN && a.saved.relu_bits && valid) ? bits_at(l - 1) : nullptr);
         RSN_T(3);
-        gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_x[l], pk + P.L.h_x[l], X, NB * 4, ln,
+        gemm_mode_run<MODE, NB, NB, TRAIN>(acc, wpre, pk + P.L.w_x[l], pk + P.L.h_x[l], X, NB * 4, ln,
                                 rb_loop(a.saved.act, (l - 1) * a.act_stride + p0 * W, W));
         RSN_T(4);
         if (l == P.skip_layer) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
           }
           X[12 * 64] = st3;
           if (MODE != 0) X[13 * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          gemm_mode_run<MODE, NB>(acc, wpre, pk + P.L.w_enc_skip, pk + P.L.h_enc_skip, X, RSN_ENC_ITS, ln);
+          gemm_mode_run<MODE, NB, NB, TRAIN>(acc, wpre, pk + P.L.w_enc_skip, pk + P.L.h_enc_skip, X, RSN_ENC_ITS, ln);
           RSN_T(2);
         }
       }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       f32x16 acc[NB + 1];
       init_acc<NB + 1>(acc, pk + P.L.b_bh, h);
       RSN_T(1);
-      gemm_mode_run<MODE, NB + 1>(acc, wbh, pk + P.L.w_bh, pk + P.L.h_bh, X, NB * 4, ln,
+      gemm_mode_run<MODE, NB + 1, NB + 1, TRAIN>(acc, wbh, pk + P.L.w_bh, pk + P.L.h_bh, X, NB * 4, ln,
                                   rb_loop(a.mode == RSN_MODE_EMB ? nullptr : a.saved.act, (P.num_layers - 1) * a.act_stride + p0 * W, W));
       RSN_T(5);
       pre_mode<MODE, 4>(wmid, pk + P.L.w_mid_sh, ln);
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       RSN_T(1);
       float4 wmx[4];
       pre_mode<MODE, 4>(wmx, pk + P.L.w_mid_x, ln);
-      gemm_mode_run<MODE, 4>(accm, wmid, pk + P.L.w_mid_sh, pk + P.L.h_mid_sh, AUX, RSN_SH_ITS, ln);
+      gemm_mode_run<MODE, 4, 4, TRAIN>(accm, wmid, pk + P.L.w_mid_sh, pk + P.L.h_mid_sh, AUX, RSN_SH_ITS, ln);
       RSN_T(7);
-      gemm_mode_run<MODE, 4>(accm, wmx, pk + P.L.w_mid_x, pk + P.L.h_mid_x, X, NB * 4, ln, rb_loop(a.saved.bott, p0 * W, W));
+      gemm_mode_run<MODE, 4, 4, TRAIN>(accm, wmx, pk + P.L.w_mid_x, pk + P.L.h_mid_x, X, NB * 4, ln, rb_loop(a.saved.bott, p0 * W, W));
       RSN_T(8);
       pre_mode<MODE, 1>(wrgb, pk + P.L.w_rgb, ln);
       store_act<4, 4, true, SBF>(accm, X, rb_epi(a.saved.hid, p0 * 128, 128), h,
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       f32x16 accr[1];
       init_acc<1>(accr, pk + P.L.b_rgb, h);
       RSN_T(1);
-      gemm_mode_run<MODE, 1>(accr, wrgb, pk + P.L.w_rgb, pk + P.L.h_rgb, X, 16, ln, rb_loop(a.saved.hid, p0 * 128, 128));
+      gemm_mode_run<MODE, 1, 1, TRAIN>(accr, wrgb, pk + P.L.w_rgb, pk + P.L.h_rgb, X, 16, ln, rb_loop(a.saved.hid, p0 * 128, 128));
       RSN_T(9);
       if (h == 1 && valid) {
         const float m0 = sigmoid_f(accr[0][0]);
@@ -381,18 +381,18 @@ __global__ __launch_bounds__(256) void rsn_field_kernel(const FieldJobs J) {
       RSN_T(13);
 #pragma unroll 1
       for (int l = P.num_layers - 1; l >= 1; --l) {
-        if (l == P.skip_layer) gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc_skip, pk + P.L.hT_enc_skip, X, NB * 4, ln);
+        if (l == P.skip_layer) gemm_mode<MODE, 4, 4, TRAIN>(eacc, pk + P.L.wT_enc_skip, pk + P.L.hT_enc_skip, X, NB * 4, ln);
         const ReluBits<NB> mb = load_relu_bits<NB>(bits_at(l - 1));
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[NB];
         zero_acc<NB>(acc);
         RSN_T(13);
-        gemm_mode<MODE, NB>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln);
+        gemm_mode<MODE, NB, NB, TRAIN>(acc, pk + P.L.wT_x[l], pk + P.L.hT_x[l], X, NB * 4, ln);
         RSN_T(12);
         store_masked_bits<NB>(acc, X, mb, h);
       }
       RSN_T(13);
-      gemm_mode<MODE, 4>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln);
+      gemm_mode<MODE, 4, 4, TRAIN>(eacc, pk + P.L.wT_enc0, pk + P.L.hT_enc0, X, NB * 4, ln);
       RSN_T(12);
       store_act<4, 4, false>(eacc, X);  // gradient w.r.t. this lane's encoded inputs, slot order (its 0..12)
       float nrm[3];

@@ -249,6 +249,53 @@ __device__ __forceinline__ void pre_w(float4 (&wa)[NBO], const float* __restrict
 // MFMA B operand), so the row leaves as ONE buffer store per K-iteration, 2,048 MFMA cycles apart -- instead of a burst
 // of 32 stores in the epilogue that produced it, which blocked the wave at the CU's 64 B/clk write port
 // (profiles/r03_store_in_loop.txt).
+// PF2: the weight fragments TWO K-iterations ahead (three fragment buffers, 4,096 MFMA cycles of cover).  The training
+// kernels stream forward AND transposed weights, 4.5 MB against the 4 MiB L2 of an XCD, so part of their stream comes from
+// beyond the L2 and one iteration of cover is short: training forward 20.9 -> 20.3 ms per step (82.2 -> 84.7 % of the
+// fp32-MFMA peak), backward 11.97 -> 11.81 ms.  The eval kernel's 2.5 MB stay in L2 and it is 1 % slower this way (4.64 ->
+// 4.70 ms): it keeps the two-buffer loop below.
+template <int NBO, int NBT = NBO, class SV = const float*>
+__device__ __forceinline__ void gemm_run2(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ wseg,
+                                           const float4* xl, int n_it, int lane, SV save = nullptr) {
+  const WBuf wp = wbuf_make(wseg, lane);
+  float4 wb[NBO], wc[NBO];
+  float4 b0, b1, b2;
+  auto cl = [&](int i) { return i < n_it ? i : n_it - 1; };
+  load_w<NBO, NBT>(wb, wp, cl(1));
+  b0 = xl[0];
+  int it = 0;
+#pragma unroll 1
+  for (; it + 2 < n_it; it += 3) {
+    load_w<NBO, NBT>(wc, wp, cl(it + 2));
+    b1 = xl[cl(it + 1) * 64];
+    mma4<NBO>(acc, wa, b0);
+    if (sv_on(save)) sv_put_it(save, it, b0);
+    interleave_loads<NBO>();
+    __builtin_amdgcn_sched_barrier(0);
+    load_w<NBO, NBT>(wa, wp, cl(it + 3));
+    b2 = xl[cl(it + 2) * 64];
+    mma4<NBO>(acc, wb, b1);
+    if (sv_on(save)) sv_put_it(save, it + 1, b1);
+    interleave_loads<NBO>();
+    __builtin_amdgcn_sched_barrier(0);
+    load_w<NBO, NBT>(wb, wp, cl(it + 4));
+    b0 = xl[cl(it + 3) * 64];
+    mma4<NBO>(acc, wc, b2);
+    if (sv_on(save)) sv_put_it(save, it + 2, b2);
+    interleave_loads<NBO>();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (it < n_it) {
+    mma4<NBO>(acc, wa, b0);
+    if (sv_on(save)) sv_put_it(save, it, b0);
+  }
+  if (it + 1 < n_it) {
+    b1 = xl[(it + 1) * 64];
+    mma4<NBO>(acc, wb, b1);
+    if (sv_on(save)) sv_put_it(save, it + 1, b1);
+  }
+}
+
 template <int NBO, int NBT = NBO, class SV = const float*>
 __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ wseg,
                                           const float4* xl, int n_it, int lane, SV save = nullptr) {
@@ -281,12 +328,12 @@ __device__ __forceinline__ void gemm_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], 
   }
 }
 
-template <int NBO, int NBT = NBO, class SV = const float*>
+template <int NBO, int NBT = NBO, bool PF2 = false, class SV = const float*>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[NBO], const float* __restrict__ wseg, const float4* xl, int n_it,
                                      int lane, SV save = nullptr) {
   float4 wa[NBO];
   pre_w<NBO, NBT>(wa, wseg, lane);
-  gemm_run<NBO, NBT>(acc, wa, wseg, xl, n_it, lane, save);
+  if (PF2) gemm_run2<NBO, NBT>(acc, wa, wseg, xl, n_it, lane, save); else gemm_run<NBO, NBT>(acc, wa, wseg, xl, n_it, lane, save);
 }
 
 // acc[nb][4q+j] = bias[nb*32 + 8q + 4h + j]: the accumulators start from the bias (what torch's addmm does),
@@ -410,12 +457,12 @@ __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NBO], const float* __res
 }
 
 // dispatch on the MMA mode: MODE 0 = fp32 MFMA over n_it K-iterations of 8, else split-bf16 over ceil(n_it/2) K=16 steps
-template <int MODE, int NBO, int NBT = NBO, class SV = const float*>
+template <int MODE, int NBO, int NBT = NBO, bool PF2 = false, class SV = const float*>
 __device__ __forceinline__ void gemm_mode(f32x16 (&acc)[NBO], const float* __restrict__ w32, const float* __restrict__ w16,
                                           const float4* xl, int n_it, int lane, SV save = nullptr) {
   static_assert(MODE == 0 || NBT == NBO, "the split-bf16 loops own every output block of their segment");
   if (MODE == 0) {
-    gemm<NBO, NBT>(acc, w32, xl, n_it, lane, save);
+    gemm<NBO, NBT, PF2>(acc, w32, xl, n_it, lane, save);
   } else {
     gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
   }
@@ -428,13 +475,13 @@ __device__ __forceinline__ void pre_mode(float4 (&wa)[NBO], const float* __restr
   if (MODE == 0) pre_w<NBO, NBT>(wa, w32, lane);
 }
 
-template <int MODE, int NBO, int NBT = NBO, class SV = const float*>
+template <int MODE, int NBO, int NBT = NBO, bool PF2 = false, class SV = const float*>
 __device__ __forceinline__ void gemm_mode_run(f32x16 (&acc)[NBO], float4 (&wa)[NBO], const float* __restrict__ w32,
                                               const float* __restrict__ w16, const float4* xl, int n_it, int lane,
                                               SV save = nullptr) {
   static_assert(MODE == 0 || NBT == NBO, "the split-bf16 loops own every output block of their segment");
-  if (MODE == 0) {
-    gemm_run<NBO, NBT>(acc, wa, w32, xl, n_it, lane, save);  // (the split-bf16 loops take no saver: their epilogues store)
+  if (MODE == 0) {  // (the split-bf16 loops take no saver: their epilogues store)
+    if (PF2) gemm_run2<NBO, NBT>(acc, wa, w32, xl, n_it, lane, save); else gemm_run<NBO, NBT>(acc, wa, w32, xl, n_it, lane, save);
   } else {
     gemm_bf16<NBO, (MODE == 1 ? 3 : (MODE == 2 ? 2 : 1))>(acc, w16, xl, (n_it + 1) / 2, lane);
   }
