@@ -393,7 +393,11 @@ __device__ __forceinline__ void load_w16(bf16x8 (&w)[NH][3], const WBuf& wp, int
   for (int t = 0; t < NH; ++t)
 #pragma unroll
     for (int sp = 0; sp < NSPLIT; ++sp) {
+#ifdef RSN_DIAG_X6_SAMEW  // timing ablation (wrong results): every K step re-reads step 0's fragments (L1 / L2 hits)
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.voff, (unsigned)(((0 * nbo + nb0 + t) * 3 + sp) * 1024), 0);
+#else
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.voff, (unsigned)(((kk * nbo + nb0 + t) * 3 + sp) * 1024), 0);
+#endif
       w[t][sp] = __builtin_bit_cast(bf16x8, v);
     }
 }
