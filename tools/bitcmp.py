@@ -1,3 +1,7 @@
+"""Writes the eval outputs of one sampling level and every parameter gradient of one training step (two weight scales, fixed
+seeds) to a .pt file; run it from two trees (the working tree and `git archive <commit>` built beside it) and compare the
+files: kernel changes that must not change the arithmetic (address paths, register allocation) give bit-identical eval tensors.
+    python tools/bitcmp.py out.pt"""
 import os, sys, torch, hashlib
 sys.path.insert(0, os.getcwd())
 import reflect_sampling_nerf_amd as pkg
