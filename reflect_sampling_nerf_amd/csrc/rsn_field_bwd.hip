@@ -165,11 +165,12 @@ __global__ __launch_bounds__(256) void rsn_field_bwd_kernel(const BwdJobs J) {
     const bool valid = p < n_points;
     const long long pc = valid ? p : n_points - 1;
     const int rows = (int)(n_points - p0 < 32 ? n_points - p0 : 32);  // valid rows of this wave's tile (wave-uniform)
-    // Layer-gradient rows kept for the weight gradients leave from the epilogue that produces them.  (The forward kernel's
-    // exact-fp32 GEMMs store the rows they READ from inside the K loop, gemm_run's `save`; the same arrangement here --
-    // LOOPST = (MODE == 0), parity green -- ran the sweeps 12.1 -> 12.5 ms per step on the same box, 12.0 -> 12.3 ms with only the
-    // trunk's dy rows in-loop, so it stays off.)
-    constexpr bool LOOPST = false;
+    // Layer-gradient rows kept for the weight gradients.  Exact fp32: a row leaves from the K loop of the GEMM that READS it
+    // (one buffer store per K-iteration, gemm_run2's `save`); the split / plain bf16 loops store from the epilogue that
+    // produces it.  History: with the two-buffer K loop this arrangement ran the sweeps 12.1 -> 12.5 ms per step (vmcnt
+    // counts stores in order with the loads, so a fragment wait also waited out the store in front of it); with the
+    // fragments two iterations ahead (gemm_run2) it is 11.78 -> 11.55 ms.
+    constexpr bool LOOPST = MODE == 0;
     auto rb_epi = [&](float* base, long long elem, int row_elems) {
       return rowbuf<SBF>(LOOPST ? nullptr : base, elem, rows, row_elems, m, h);
     };
