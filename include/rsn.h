@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 13
+#define RSN_ABI_VERSION 14
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -423,6 +423,23 @@ int rsn_weight_grad_multi_dev(int32_t n_segments, const int64_t* n_points_max, c
                               const int32_t* per_count, const float* const* dy, int32_t ld_dy, int32_t n_out,
                               const float* const* x, int32_t ld_x, int32_t k_in, const int32_t* col_map, float* dw,
                               int32_t ld_dw, float* db, int32_t mma_mode, int32_t operand_bf16, void* stream);
+
+/* Several weight-gradient reductions of ONE shape over the SAME segments in one launch (the trunk layers of a training step:
+ * 256 x 256 each, reference autograd of reflect_sampling_nerf_field.py:54-60's MLP).  The workgroups are dealt to the jobs
+ * round-robin; every workgroup still flushes one output tile, so n_jobs layers pay ONE atomic-flush phase and one launch
+ * ramp.  dy[s] / x[s]: the job's rows of segment s (HOST arrays of n_segments device pointers); other arguments as
+ * rsn_weight_grad_multi_dev. */
+typedef struct rsn_wgrad_job {
+  const float* const* dy;  /* [n_segments] -> [n_s, ld_dy]                        */
+  const float* const* x;   /* [n_segments] -> [n_s, ld_x]                         */
+  const int32_t* col_map;  /* optional: packed column k -> destination column / -1 */
+  float* dw;               /* [n_out, ld_dw], accumulated                          */
+  int32_t ld_dw;
+  float* db;               /* [n_out] or NULL, accumulated                         */
+} rsn_wgrad_job;
+int rsn_weight_grad_jobs(int32_t n_segments, const int64_t* n_points_max, const int32_t* const* n_dev,
+                         const int32_t* per_count, int32_t n_jobs, const rsn_wgrad_job* jobs, int32_t ld_dy, int32_t n_out,
+                         int32_t ld_x, int32_t k_in, int32_t mma_mode, int32_t operand_bf16, void* stream);
 
 /* get_loss_dict on per-ray quantities only (training step: the per-sample normal terms arrive reduced per ray from
  * rsn_composite): losses8[k] = the UNSCALED terms (0-3 MSE means of rgb4[k] against image; 4,5 = sum_r pn_loss_ray2[lv][r];

@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 13
+RSN_ABI_VERSION = 14
 RSN_ABI_DIAG_FLAG = 0x10000  # rsn_abi_version() of a -DRSN_DIAG_BUILD library (csrc/rsn_common.h)
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
@@ -81,6 +81,12 @@ class FieldBwdJob(C.Structure):
                 ("saved", C.POINTER(FieldSaved)), ("gin", C.POINTER(FieldGradsIn)), ("gout", C.POINTER(FieldGradsOut))]
 
 
+class WGradJob(C.Structure):
+    """rsn_wgrad_job: one reduction of a job-parallel weight-gradient launch (rsn_weight_grad_jobs)."""
+    _fields_ = [("dy", C.POINTER(C.c_void_p)), ("x", C.POINTER(C.c_void_p)), ("col_map", C.c_void_p), ("dw", C.c_void_p),
+                ("ld_dw", C.c_int32), ("db", C.c_void_p)]
+
+
 class CompositeBwdIO(C.Structure):
     _fields_ = [(n, _fp) for n in ("sigma", "euclid_bins", "color", "bg_rgb", "roughness", "weights", "g_rgb",
                                    "g_roughness", "g_accumulation", "g_sigma", "g_color", "g_roughness_sample",
@@ -143,6 +149,9 @@ _SIGNATURES = {
     "rsn_weight_grad_multi_dev": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                             C.c_int32, _fp, C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_void_p]),
+    "rsn_weight_grad_jobs": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32,
+                                       C.POINTER(WGradJob), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p]),
     "rsn_loss_forward_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, C.POINTER(_fp), C.POINTER(_fp),
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_float), _fp,
                                             C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.c_void_p]),

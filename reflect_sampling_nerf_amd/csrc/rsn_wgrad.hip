@@ -36,6 +36,15 @@ struct WGradArgs {
   float* db;           // [n_out] or NULL, accumulated
 };
 
+// Several reductions of the SAME shape (n_out, k_in, leading dimensions, operand types) and the same segment lengths in
+// one launch: workgroup i works on job i % n_jobs with the other gridDim / n_jobs - 1 workgroups of that job.  Every
+// workgroup still flushes one tile, so the launch pays ONE flush phase (and one ramp) for n_jobs layers.
+#define WG_MAX_JOBS 8
+struct WGradJobs {
+  int n_jobs;
+  WGradArgs j[WG_MAX_JOBS];
+};
+
 #ifndef WG_PAIRS
 #define WG_PAIRS 4  // point pairs (MFMA K-steps) per software-pipeline stage
 #endif
@@ -52,7 +61,9 @@ struct WGradArgs {
 //          bf16: rsn_field_saved, rsn_field_grads_out): half the bytes of this HBM-bound variant, no conversion; a lane's
 //          8 points x {2 rows | NKB columns} arrive as packed words and are regrouped per row / column by v_perm_b32.
 template <int NKB, bool XV, bool DV, int BF = 0, bool XB = false, bool DB = false>
-__global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
+__global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
+  const int n_jobs = J.n_jobs;
+  const WGradArgs& a = J.j[blockIdx.x % n_jobs];  // workgroup-uniform
   static_assert(!(XB || DB) || (BF == 1 && XV), "bf16 rows: the plain-bf16 variant with vector loads of X only");
   static_assert(!DB || DV, "bf16 dY rows come as (row 2i, row 2i+1) pairs");
   constexpr int NP = BF ? 8 : WG_PAIRS;  // points per lane and stage
@@ -74,8 +85,8 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   // part, 246 us with the loads removed: the four waves of a workgroup each fetch the whole X row (L1 only partly
   // dedups them), ~10 B/cycle/CU of fill traffic, the per-CU streaming limit.  Sharing X through LDS would halve
   // that; not done yet.
-  const long long G = (long long)gridDim.x * nsub;
-  const long long g = (long long)blockIdx.x * nsub + sub;
+  const long long G = (long long)(gridDim.x / n_jobs) * nsub;  // wave slots of this job
+  const long long g = (long long)(blockIdx.x / n_jobs) * nsub + sub;
   const bool t1_live = DV || (nb0 + 1) * 32 < a.n_out;  // wave-uniform: second row block holds live rows
 
   f32x16 acc[2][NKB];
@@ -496,7 +507,8 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradArgs a) {
   }
 }
 
-static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0, int operand_bf16 = 0) {
+static int wgrad_launch(WGradJobs& J, void* stream, int mode = 0, int operand_bf16 = 0) {
+  WGradArgs& a = J.j[0];  // the jobs of a launch share shape, leading dimensions and segment lengths (checked by the caller)
   const bool xb = (operand_bf16 & 1) != 0, db = (operand_bf16 & 2) != 0;  // rows that ARE bf16 in memory
   bool bf16 = mode == RSN_MMA_BF16 || mode == RSN_MMA_BF16X6;
   const long long total = a.seg_begin[a.n_seg];
@@ -508,10 +520,11 @@ static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0, int operand_bf
   // vector-load variants need whole NKB-column groups and aligned rows; anything else takes the scalar-load path
   bool xv = a.k_in % nkb == 0 && a.ld_x % (xb ? nkb : (nkb >= 4 ? 4 : 2)) == 0;
   bool dv = a.n_out > 32 && a.ld_dy % 2 == 0 && a.ld_dy >= a.n_out + (a.n_out & 1);
-  for (int s = 0; s < a.n_seg; ++s) {
-    xv = xv && ((uintptr_t)a.x[s] % (xb ? 2 * nkb : 16) == 0);
-    dv = dv && ((uintptr_t)a.dy[s] % (db ? 4 : 8) == 0);
-  }
+  for (int jb = 0; jb < J.n_jobs; ++jb)
+    for (int s = 0; s < a.n_seg; ++s) {
+      xv = xv && ((uintptr_t)J.j[jb].x[s] % (xb ? 2 * nkb : 16) == 0);
+      dv = dv && ((uintptr_t)J.j[jb].dy[s] % (db ? 4 : 8) == 0);
+    }
   if (xb || db) {  // no other kernel can read bf16 rows: the layout must fit, loudly
     RSN_REQUIRE(mode == RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "bf16 operand rows need mma_mode RSN_MMA_BF16");
     RSN_REQUIRE(xv && (!db || dv), RSN_ERR_UNSUPPORTED,
@@ -530,30 +543,31 @@ static int wgrad_launch(WGradArgs& a, void* stream, int mode = 0, int operand_bf
   const double t_stage = bf16 ? (a.n_out > 32 ? 2 : 1) * nkb_ * 32 / 1.9e9 * (mode == RSN_MMA_BF16X6 ? 6 : 2.5)  // 1 product: HBM-bound, ~2.5x the MFMA time
                               : WG_PAIRS * (a.n_out > 32 ? 2 : 1) * nkb_ * 64 / 2.1e9;
   const double t_flush = (double)a.n_out * a.k_in * 4.0 / 1.3e12 + 2e-8;
-  long long grid = (long long)(sqrt((double)stages * t_stage / (nsub * t_flush)) + 0.5);
-  if (grid > cached_cus) grid = cached_cus;
+  long long grid = (long long)(sqrt((double)stages * t_stage / (nsub * t_flush)) + 0.5);  // workgroups per job
+  if (grid > cached_cus / J.n_jobs) grid = cached_cus / J.n_jobs;
   if (grid < 1) grid = 1;
+  grid *= J.n_jobs;  // workgroup i: job i % n_jobs
   hipStream_t st = (hipStream_t)stream;
 #define RSN_WG(NKBV)                                                                                           \
   do {                                                                                                         \
     if (xv && dv && bf16 && mode == RSN_MMA_BF16X6)                                                            \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, a);  \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 3>), dim3((unsigned)grid), dim3(256), 0, st, J);  \
     else if (bf16 && xb && db)                                                                                 \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1, true, true>), dim3((unsigned)grid), dim3(256), 0, st, J); \
     else if (bf16 && db)                                                                                       \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, st, J); \
     else if (bf16 && xb && !dv)                                                                                \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, false, 1, true, false>), dim3((unsigned)grid), dim3(256), 0, st, a); \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, false, 1, true, false>), dim3((unsigned)grid), dim3(256), 0, st, J); \
     else if (bf16 && xb)                                                                                       \
       { RSN_REQUIRE(false, RSN_ERR_UNSUPPORTED, "bf16 X rows with fp32 dY rows wider than 32 outputs"); }      \
     else if (xv && dv && bf16)                                                                                 \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);  \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, J);  \
     else if (xv && dv)                                                                                         \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true>), dim3((unsigned)grid), dim3(256), 0, st, a);     \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, true>), dim3((unsigned)grid), dim3(256), 0, st, J);     \
     else if (xv)                                                                                               \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, false>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, true, false>), dim3((unsigned)grid), dim3(256), 0, st, J);    \
     else                                                                                                       \
-      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, false, false>), dim3((unsigned)grid), dim3(256), 0, st, a);   \
+      hipLaunchKernelGGL((rsn_wgrad_kernel<NKBV, false, false>), dim3((unsigned)grid), dim3(256), 0, st, J);   \
   } while (0)
   if (nkb == 8)
     RSN_WG(8);
@@ -589,7 +603,9 @@ static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, c
   RSN_REQUIRE(ld_dy >= n_out && ld_x >= k_in && ld_dw >= 1, RSN_ERR_INVALID_ARGUMENT, "leading dimensions too small");
   if (n_segments == 0) return RSN_OK;
   RSN_REQUIRE(n_points && dy && x && dw, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
-  WGradArgs a = {};
+  WGradJobs J = {};
+  J.n_jobs = 1;
+  WGradArgs& a = J.j[0];
   a.seg_begin[0] = 0;
   int ns = 0;
   for (int s = 0; s < n_segments; ++s) {
@@ -607,7 +623,7 @@ static int weight_grad_multi_impl(int32_t n_segments, const int64_t* n_points, c
   a.n_seg = ns;
   a.ld_dy = ld_dy; a.ld_x = ld_x; a.n_out = n_out; a.k_in = k_in;
   a.ld_dw = ld_dw; a.col_map = col_map; a.dw = dw; a.db = db;
-  return wgrad_launch(a, stream, mode, operand_bf16);
+  return wgrad_launch(J, stream, mode, operand_bf16);
 }
 
 extern "C" int rsn_weight_grad_multi_mode(int32_t n_segments, const int64_t* n_points, const float* const* dy,
@@ -629,6 +645,49 @@ extern "C" int rsn_weight_grad_multi_dev(int32_t n_segments, const int64_t* n_po
   RSN_REQUIRE(operand_bf16 >= 0 && operand_bf16 <= 3, RSN_ERR_INVALID_ARGUMENT, "operand_bf16 %d", operand_bf16);
   return weight_grad_multi_impl(n_segments, n_points_max, dy, ld_dy, n_out, x, ld_x, k_in, col_map, dw, ld_dw, db, stream,
                                 mma_mode, n_dev, per_count, operand_bf16);
+}
+
+// rsn_weight_grad_jobs: n_jobs reductions of one shape over the same segments in ONE launch (see WGradJobs).
+extern "C" int rsn_weight_grad_jobs(int32_t n_segments, const int64_t* n_points_max, const int32_t* const* n_dev,
+                                    const int32_t* per_count, int32_t n_jobs, const rsn_wgrad_job* jobs, int32_t ld_dy,
+                                    int32_t n_out, int32_t ld_x, int32_t k_in, int32_t mma_mode, int32_t operand_bf16,
+                                    void* stream) {
+  RSN_REQUIRE(mma_mode >= RSN_MMA_F32 && mma_mode <= RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "mma_mode %d", mma_mode);
+  RSN_REQUIRE(operand_bf16 >= 0 && operand_bf16 <= 3, RSN_ERR_INVALID_ARGUMENT, "operand_bf16 %d", operand_bf16);
+  RSN_REQUIRE(n_jobs >= 1 && n_jobs <= WG_MAX_JOBS && jobs, RSN_ERR_INVALID_ARGUMENT, "n_jobs=%d (1..%d)", n_jobs, WG_MAX_JOBS);
+  RSN_REQUIRE(n_segments >= 0 && n_segments <= WG_MAX_SEG, RSN_ERR_INVALID_ARGUMENT, "n_segments=%d (at most %d)",
+              n_segments, WG_MAX_SEG);
+  RSN_REQUIRE(n_out >= 1 && n_out <= 256 && k_in >= 1 && k_in <= 256, RSN_ERR_INVALID_ARGUMENT,
+              "n_out=%d k_in=%d (outputs up to 256 x 256)", n_out, k_in);
+  RSN_REQUIRE(ld_dy >= n_out && ld_x >= k_in, RSN_ERR_INVALID_ARGUMENT, "leading dimensions too small");
+  if (n_segments == 0) return RSN_OK;
+  RSN_REQUIRE(n_points_max, RSN_ERR_INVALID_ARGUMENT, "n_points_max is NULL");
+  WGradJobs J = {};
+  J.n_jobs = n_jobs;
+  for (int jb = 0; jb < n_jobs; ++jb) {
+    const rsn_wgrad_job& q = jobs[jb];
+    WGradArgs& a = J.j[jb];
+    RSN_REQUIRE(q.dy && q.x && q.dw && q.ld_dw >= 1, RSN_ERR_INVALID_ARGUMENT, "job %d: a pointer is NULL / ld_dw=%d", jb, q.ld_dw);
+    a.seg_begin[0] = 0;
+    int ns = 0;
+    for (int s = 0; s < n_segments; ++s) {
+      RSN_REQUIRE(n_points_max[s] >= 0, RSN_ERR_INVALID_ARGUMENT, "n_points_max[%d]=%lld", s, (long long)n_points_max[s]);
+      if (n_points_max[s] == 0) continue;
+      RSN_REQUIRE(q.dy[s] && q.x[s], RSN_ERR_INVALID_ARGUMENT, "job %d segment %d: a pointer is NULL", jb, s);
+      a.dy[ns] = q.dy[s];
+      a.x[ns] = q.x[s];
+      a.seg_begin[ns + 1] = a.seg_begin[ns] + n_points_max[s];
+      a.n_dev[ns] = n_dev ? n_dev[s] : nullptr;
+      a.per_count[ns] = (n_dev && n_dev[s] && per_count) ? per_count[s] : 1;
+      RSN_REQUIRE(a.per_count[ns] >= 1, RSN_ERR_INVALID_ARGUMENT, "segment %d: per_count=%d", s, a.per_count[ns]);
+      ++ns;
+    }
+    a.n_seg = ns;
+    a.ld_dy = ld_dy; a.ld_x = ld_x; a.n_out = n_out; a.k_in = k_in;
+    a.ld_dw = q.ld_dw; a.col_map = q.col_map; a.dw = q.dw; a.db = q.db;
+  }
+  if (J.j[0].n_seg == 0) return RSN_OK;
+  return wgrad_launch(J, stream, mma_mode, operand_bf16);
 }
 
 extern "C" int rsn_weight_grad(int64_t n_points, const float* dy, int32_t ld_dy, int32_t n_out, const float* x,

@@ -145,6 +145,7 @@ def _wgrad(dy: Tensor, n_out: int, x: Tensor, k_in: int, dw: Tensor, dw_col0: in
 
 
 _WGRAD_MODE = 0  # RSN_MMA_*: set per step by _weight_grads from the Field's MMA mode
+_WGRAD_JOBS_MAX = 8  # WG_MAX_JOBS of rsn_wgrad.hip
 
 
 def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Optional[Tensor],
@@ -179,6 +180,47 @@ def _wgrad_multi(segs, n_out: int, k_in: int, dw: Tensor, dw_col0: int, db: Opti
                                                           dwp, dw.stride(0), ptr(db), _WGRAD_MODE, operand_bf16, ops._stream())))
 
 
+def _wgrad_jobs(jobs, n_out: int, k_in: int):
+    """Several weight-gradient reductions of ONE shape in one launch (rsn_weight_grad_jobs): jobs = [(segs, dw, dw_col0, db[, col_map])]
+    with segs as _wgrad_multi takes them, the same segment lengths / counts / leading dimensions / dtypes in every job.
+    The workgroups are dealt to the jobs; the launch pays one atomic-flush phase and one ramp for all of them."""
+    lib = _abi.load_library()
+    jobs = [(jb[0], jb[1], jb[2], jb[3], jb[4] if len(jb) > 4 else None) for jb in jobs]
+    keep = [i for i, sg in enumerate(jobs[0][0]) if sg[0].shape[0] > 0]
+    if not keep:
+        return
+    ns = len(keep)
+    ref = [jobs[0][0][i] for i in keep]
+    ld_dy, ld_x = ref[0][0].stride(0), ref[0][1].stride(0)
+    bf = torch.bfloat16
+    operand_bf16 = (1 if ref[0][1].dtype == bf else 0) | (2 if ref[0][0].dtype == bf else 0)
+    npts = (C.c_int64 * ns)(*[sg[0].shape[0] for sg in ref])
+    cnt = [sg[2] if len(sg) > 2 else None for sg in ref]
+    ndev = (C.c_void_p * ns)(*[None if c is None else c[0].data_ptr() for c in cnt])
+    per = (C.c_int32 * ns)(*[1 if c is None else int(c[1]) for c in cnt])
+    arr = (_abi.WGradJob * len(jobs))()
+    hold = []  # the pointer arrays must outlive the call
+    for q, (segs_, dw, c0, db, cmap) in zip(arr, jobs):
+        sel = [segs_[i] for i in keep]
+        assert all(a[0].shape[0] == b[0].shape[0] and a[0].stride(0) == ld_dy and a[1].stride(0) == ld_x and
+                   a[0].dtype == b[0].dtype and a[1].dtype == b[1].dtype for a, b in zip(sel, ref))
+        dys = (C.c_void_p * ns)(*[sg[0].data_ptr() for sg in sel])
+        xs = (C.c_void_p * ns)(*[sg[1].data_ptr() for sg in sel])
+        hold += [dys, xs]
+        q.dy, q.x = dys, xs
+        q.col_map = None if cmap is None else cmap.data_ptr()
+        q.dw = dw.data_ptr() + 4 * c0
+        q.ld_dw = dw.stride(0)
+        q.db = None if db is None else db.data_ptr()
+    work = {"point_out_in": len(jobs) * sum(sg[0].shape[0] for sg in ref if len(sg) < 3 or sg[2] is None) * n_out * k_in}
+    dev_work = [(c[0], len(jobs) * c[1] * n_out * k_in) for c in cnt if c is not None]
+    if dev_work:
+        work["point_out_in_dev"] = dev_work
+    ops.timed("weight_grad", work,
+              lambda: check(lib.rsn_weight_grad_jobs(ns, npts, ndev, per, len(jobs), arr, ld_dy, n_out, ld_x, k_in,
+                                                     _WGRAD_MODE, operand_bf16, ops._stream())))
+
+
 def _weight_grads(field, levels, acc: _GradAcc):
     """dW = dY^T X (+ db) for every linear layer, reduced over all field evaluations of the step at once.
     levels: list of (saved activations, backward-sweep outputs, with_heads[, (device count, rows per count)]).  Buffers of an
@@ -195,17 +237,22 @@ def _weight_grads(field, levels, acc: _GradAcc):
     def segs(pick, only_heads=False):
         return [(*pick(lv[0], lv[1]), c) for lv, c in zip(levels, cnt) if lv[2] or not only_heads]
 
+    # the W x W reductions (trunk layers >= 1 and the bottleneck) share one shape: one job-parallel launch per <= 8 of them
+    ww, we = [], []  # (W x W) and (W x encoded inputs) jobs
     for l in range(L):
         gw, gb = g[f"mlp_base.layers.{l}.weight"], g[f"mlp_base.layers.{l}.bias"]
         if l == 0:
-            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["enc"])), W, ENC_SLOTS, gw, 0, gb, enc_map)
+            we.append((segs(lambda sv, go: (go["dy"][l], sv["enc"])), gw, 0, gb, enc_map))
         elif l == skip:
-            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["enc"])), W, ENC_SLOTS, gw, 0, gb, enc_map)
-            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["act"][l - 1])), W, W, gw, 99, None)
+            we.append((segs(lambda sv, go: (go["dy"][l], sv["enc"])), gw, 0, gb, enc_map))
+            ww.append((segs(lambda sv, go: (go["dy"][l], sv["act"][l - 1])), gw, 99, None))
         else:
-            _wgrad_multi(segs(lambda sv, go: (go["dy"][l], sv["act"][l - 1])), W, W, gw, 0, gb)
-    _wgrad_multi(segs(lambda sv, go: (go["d_bott"], sv["act"][L - 1])), W, W, g["field_output_bottleneck.net.weight"], 0,
-                 g["field_output_bottleneck.net.bias"])
+            ww.append((segs(lambda sv, go: (go["dy"][l], sv["act"][l - 1])), gw, 0, gb))
+    ww.append((segs(lambda sv, go: (go["d_bott"], sv["act"][L - 1])), g["field_output_bottleneck.net.weight"], 0,
+               g["field_output_bottleneck.net.bias"]))
+    _wgrad_jobs(we, W, ENC_SLOTS)
+    for i in range(0, len(ww), _WGRAD_JOBS_MAX):
+        _wgrad_jobs(ww[i:i + _WGRAD_JOBS_MAX], W, W)
     _wgrad_multi(segs(lambda sv, go: (go["da_mid"], sv["sh"])), 128, SH_SLOTS, g["mlp_mid.layers.0.weight"], 0,
                  g["mlp_mid.layers.0.bias"], sh_map)
     _wgrad_multi(segs(lambda sv, go: (go["da_mid"], sv["bott"])), 128, W, g["mlp_mid.layers.0.weight"], 34, None)

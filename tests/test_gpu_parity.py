@@ -976,6 +976,51 @@ def test_weight_grad_bf16_rows(dev, monkeypatch, n_out, k_in, x_bf16, dy_bf16):
     assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])  # exact fp32, split-bf16 (fp32-equivalent)
+@pytest.mark.parametrize("n_jobs,n_out,k_in", [(8, 256, 256), (3, 256, 256), (2, 256, 104), (5, 64, 64)])
+def test_weight_grad_jobs_equal_separate_launches(dev, monkeypatch, mode, n_jobs, n_out, k_in):
+    """rsn_weight_grad_jobs: several reductions of one shape over the same segments (one cut by a DEVICE-side count) in ONE
+    launch -- the workgroups are dealt to the jobs, each flushes one tile -- against the fp64 products, the bound of the
+    single-job kernel; the destination column offset / column map / missing bias of a job are its own
+    (reference: autograd of the trunk's Linear layers, reflect_sampling_nerf_field.py:54-60)."""
+    from reflect_sampling_nerf_amd import train_graph
+
+    g = torch.Generator().manual_seed(31 * n_jobs + k_in + mode)
+    lens = [700, 33, 2051, 640]
+    count = torch.tensor([7], dtype=torch.int32, device=dev)  # the last segment holds 7 x 64 = 448 of its 640 rows
+    cmap = torch.randperm(k_in, generator=g).to(torch.int32).to(dev) if k_in == 104 else None
+    jobs, refs = [], []
+    for jb in range(n_jobs):
+        segs = []
+        ref_w, ref_b = torch.zeros(n_out, k_in, dtype=torch.float64), torch.zeros(n_out, dtype=torch.float64)
+        for si, n in enumerate(lens):
+            dy, x = torch.randn(n, n_out, generator=g), torch.randn(n, k_in, generator=g)
+            live = 448 if si == 3 else n
+            ref_w += dy[:live].double().t() @ x[:live].double()
+            ref_b += dy[:live].double().sum(0)
+            segs.append((dy.to(dev), x.to(dev), (count, 64)) if si == 3 else (dy.to(dev), x.to(dev)))
+        c0 = 5 if jb == 1 else 0                      # job 1 lands at a column offset of a wider matrix ...
+        dw = torch.zeros(n_out, k_in + c0, device=dev)
+        db = None if jb == 1 else torch.zeros(n_out, device=dev)   # ... and has no bias
+        jobs.append((segs, dw, c0, db, cmap))
+        refs.append((ref_w, ref_b, c0))
+    monkeypatch.setattr(train_graph, "_WGRAD_MODE", mode)
+    train_graph._wgrad_jobs(jobs, n_out, k_in)
+    for (segs, dw, c0, db, _), (ref_w, ref_b, _) in zip(jobs, refs):
+        got = dw[:, c0:].double().cpu()
+        if cmap is not None:
+            exp = torch.zeros_like(ref_w)
+            exp[:, cmap.cpu().long()] = ref_w
+        else:
+            exp = ref_w
+        assert float((got - exp).abs().max()) <= 2e-5 * float(ref_w.abs().max())
+        if c0:
+            assert float(dw[:, :c0].abs().max()) == 0.0
+        if db is not None:
+            assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+
+
 def test_standalone_sh34_encoding_matches_reference_golden(dev):
     """IntegratedSHEncoding called as a module (rsn_sh34_encode) against the output of the reference's own
     IntegratedSHEncoding.forward (tests/golden/units.npz, oracle/make_golden.py) and against the oracle."""
