@@ -31,8 +31,10 @@
 
 void rsn_set_error(const char* fmt, ...);
 int rsn_device_cus();                   // CU count of the current device (cached per device)
+#ifdef RSN_DIAG_BUILD
 bool rsn_env_flag(const char* name);
-int rsn_env_int(const char* name, int dflt);    // tools: A/B switches from the environment
+int rsn_env_int(const char* name, int dflt);    // tools: A/B switches from the environment (diagnostic builds only)
+#endif
 
 #define RSN_REQUIRE(cond, code, ...)        \
   do {                                      \

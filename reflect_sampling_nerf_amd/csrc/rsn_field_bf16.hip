@@ -501,6 +501,7 @@ __device__ __forceinline__ void acc_to_x(f32x16 (&acc)[NBO], bf16x8 (&X)[XN], co
   }
 }
 
+#ifdef RSN_DIAG_BUILD  // the 32x32x16 form of the ring kernel: A/B reference of tools/ring_ab.sh only, never in librsn_hip.so
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const FieldArgs a) {
   constexpr int NB = 8, W = 256;
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rsn_field_bf16_ring_kernel(const F
   // no LDS-DMA may outlive the workgroup's LDS allocation
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#endif  // RSN_DIAG_BUILD
 
 // ================================================================================================
 // The same ring on v_mfma_f32_16x16x32_bf16.  Same FLOP per cycle as 32x32x16, but the chip holds a higher clock on
@@ -1158,33 +1160,40 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_ring16_kernel(const Fie
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-// called by launch_field (rsn_field.hip) for RSN_MMA_BF16 eval launches
+// called by launch_field (rsn_field.hip) for RSN_MMA_BF16 eval launches.  The product library takes NO run-time switches from
+// the environment; the A/B switches of tools/ (per-wave stream, start stagger, the 32x32x16 ring) exist in diagnostic
+// builds only (-DRSN_DIAG_BUILD, tools/_variant.py).
 int rsn_launch_field_bf16(int width, long long grid, hipStream_t st, const FieldArgs& a) {
-  static const bool per_wave_stream = getenv("RSN_BF16_PER_WAVE_STREAM") != nullptr;  // A/B switch for tools/
+#ifdef RSN_DIAG_BUILD
+  static const bool per_wave_stream = getenv("RSN_BF16_PER_WAVE_STREAM") != nullptr;
+  static const int stagger = getenv("RSN_RING_STAGGER") ? atoi(getenv("RSN_RING_STAGGER")) : 0;
+  static const bool shape32 = getenv("RSN_RING_SHAPE32") != nullptr;
+#else
+  constexpr bool per_wave_stream = false;
+  constexpr int stagger = 0;
+#endif
   switch (width) {
     case 256:
       // full network evaluations run on the shared LDS weight ring; the granular heads-only mode (a caller-supplied
       // embedding skips the trunk, i.e. most of the stream) keeps the per-wave stream
-      if (a.mode != RSN_MODE_EMB && a.L.r_stream != 0 && a.num_layers <= RING_MAX_LAYERS && !per_wave_stream &&
+      if (a.mode != RSN_MODE_EMB && a.L.q_stream != 0 && a.num_layers <= RING_MAX_LAYERS && !per_wave_stream &&
           (long long)a.n_rays * a.S < (1LL << 31)) {
-        static const int stagger = getenv("RSN_RING_STAGGER") ? atoi(getenv("RSN_RING_STAGGER")) : 0;
-        static const int nw = getenv("RSN_RING_WAVES") ? atoi(getenv("RSN_RING_WAVES")) : 8;
         FieldArgs b = a;
-        b.stagger = stagger;  // start skew between the workgroups of an XCD, x ~1K cycles x index (tools/ring_sweep.sh)
+        b.stagger = stagger;  // (diagnostic builds) start skew between the workgroups of an XCD (tools/ring_sweep.sh)
         const long long n_points = (long long)a.n_rays * a.S;
-        (void)nw;
-        {  // one 8-wave workgroup per CU, 256-point tiles
-          static const bool shape32 = getenv("RSN_RING_SHAPE32") != nullptr;  // A/B switch for tools/
-          const long long t8 = (n_points + 255) / 256;
-          const long long g8 = t8 < (grid + 1) / 2 ? t8 : (grid + 1) / 2;
-          if (a.L.q_stream != 0 && !shape32)
-            hipLaunchKernelGGL(rsn_field_bf16_ring16_kernel, dim3((unsigned)g8), dim3(512), 0, st, b);
-          else
-            hipLaunchKernelGGL(rsn_field_bf16_ring_kernel<8>, dim3((unsigned)g8), dim3(512), 0, st, b);
+        // one 8-wave workgroup per CU, 256-point tiles
+        const long long t8 = (n_points + 255) / 256;
+        const long long g8 = t8 < (grid + 1) / 2 ? t8 : (grid + 1) / 2;
+#ifdef RSN_DIAG_BUILD
+        if (shape32 && a.L.r_stream != 0) {
+          hipLaunchKernelGGL(rsn_field_bf16_ring_kernel<8>, dim3((unsigned)g8), dim3(512), 0, st, b);
+          break;
         }
-      }
-      else
+#endif
+        hipLaunchKernelGGL(rsn_field_bf16_ring16_kernel, dim3((unsigned)g8), dim3(512), 0, st, b);
+      } else {
         hipLaunchKernelGGL((rsn_field_bf16_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      }
       break;
     case 128: hipLaunchKernelGGL((rsn_field_bf16_kernel<4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
     case 64: hipLaunchKernelGGL((rsn_field_bf16_kernel<2>), dim3((unsigned)grid), dim3(256), 0, st, a); break;

@@ -39,6 +39,7 @@ int rsn_device_cus() {
   return cache[dev];
 }
 
+#ifdef RSN_DIAG_BUILD  // environment A/B switches exist in diagnostic builds only: the product library reads none
 int rsn_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v != nullptr && v[0] != '\0') ? atoi(v) : dflt;
@@ -54,6 +55,7 @@ bool rsn_env_flag(const char* name) {
   last_val = v != nullptr && v[0] != '\0' && v[0] != '0';
   return last_val;
 }
+#endif
 #ifdef RSN_DIAG_BUILD
 extern "C" int rsn_abi_version(void) { return RSN_ABI_VERSION | RSN_ABI_DIAG_FLAG; }  // never the product library
 #else

@@ -476,14 +476,16 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
     cdst[kb] = -1;
     if (k < a.k_in) cdst[kb] = a.col_map ? a.col_map[k] : k;
   }
-  // buffer atomics: descriptor over the n_out live rows of dW, the row's wave-uniform part in the scalar offset, one
-  // loop-invariant 32-bit lane offset per column block (lane half -> row part, destination column); rows >= n_out and
-  // padded columns fall outside the descriptor's range / get an out-of-range offset and are dropped by the hardware
+  // buffer atomics: descriptor over the n_out live rows of dW; the lane's WHOLE byte offset (row and column) travels in
+  // the vector offset -- the one operand the hardware range-checks against num_records (the scalar offset is added after
+  // the check), so rows >= n_out (clamped duplicates of live rows, non-zero) are dropped whatever lies behind dW's n_out
+  // rows (in the training step: the next parameter's gradient in the flat buffer); padded columns get an offset far
+  // past the descriptor (no 32-bit wrap with the row part: rows * ld_dw * 4 < 2^30)
   const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc(a.dw, 0, a.n_out * a.ld_dw * 4, 0x00020000);
   unsigned vdw[NKB];
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
-    vdw[kb] = cdst[kb] >= 0 ? (unsigned)(((DV ? 8 : 4) * h * a.ld_dw + cdst[kb]) * 4) : 0x40000000u;  // far past the descriptor, no 32-bit wrap with the scalar row offset
+    vdw[kb] = cdst[kb] >= 0 ? (unsigned)(((DV ? 8 : 4) * h * a.ld_dw + cdst[kb]) * 4) : 0x40000000u;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (t == 1 && !t1_live) continue;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         const float v = trw[kb * 32 + i];
-        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rdw, vdw[kb], (unsigned)(n0 * a.ld_dw * 4), 0);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rdw, vdw[kb] + (unsigned)(n0 * a.ld_dw * 4), 0u, 0);
       }
     }
     if (a.db) {

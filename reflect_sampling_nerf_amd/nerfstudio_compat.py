@@ -141,7 +141,7 @@ except ImportError:
 
         @torch.no_grad()
         def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle) -> Dict[str, Tensor]:
-            """Chunked full-image rendering (eval_num_rays_per_chunk rays per forward)."""
+            """Chunked full-image rendering (eval_num_rays_per_chunk rays per forward), as nerfstudio's base Model does it."""
             chunk = self.config.eval_num_rays_per_chunk
             image_shape = camera_ray_bundle.origins.shape[:-1]
             n = int(torch.tensor(image_shape).prod())
@@ -153,6 +153,4 @@ except ImportError:
                 for k, v in self.forward(rb).items():
                     if isinstance(v, Tensor) and v.shape[:1] == (len(rb),):
                         lists.setdefault(k, []).append(v)
-            # per-ray outputs only: a key that is not [rays, ...] in every chunk (depth_reflect_fine is [M,1]) is no image
-            return {k: torch.cat(v).view(*image_shape, *v[0].shape[1:]) for k, v in lists.items()
-                    if len(v) == n_chunks and k != "depth_reflect_fine"}
+            return {k: torch.cat(v).view(*image_shape, *v[0].shape[1:]) for k, v in lists.items() if len(v) == n_chunks}

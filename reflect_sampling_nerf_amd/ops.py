@@ -195,3 +195,66 @@ def ipe_encode(means: Tensor, covs: Optional[Tensor], freqs: Tensor) -> Tensor:
     out = torch.empty(n, 99, device=m.device, dtype=torch.float32)
     check(lib.rsn_ipe_encode(n, ptr(m), ptr(cd), fr, ptr(out), _stream()))
     return out.reshape(*lead, 99)
+
+
+class LazyOutputs(dict):
+    """The output dict of get_outputs (training and eval).  One key of the reference needs the reflected-ray count M on
+    the host: `depth_reflect_fine`, [M, 1], present only when M > 0 (reference model.py:341).  Here M lives on the device,
+    so that entry is materialised on FIRST USE: `d["depth_reflect_fine"]`, `in`, `get`, and every way of looking at the
+    dict as a whole -- `keys()`, `items()`, `values()`, iteration, `len()`, `dict(d)`, `copy()` -- so a generic consumer
+    (metrics, loggers, dict copies) sees exactly the reference's key set.  That first use is one device-to-host read; a
+    training step or a chunked image render that only indexes the keys it needs performs none.  `present()` lists what is
+    there WITHOUT materialising (the renderer's own chunk loop uses it)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.lazy: Dict[str, tuple] = {}
+        self.fused: Optional[Dict[str, Tensor]] = None  # per-ray loss reductions for get_loss_dict (training graph)
+
+    def _materialise(self, key):
+        count, per_ray = self.lazy.pop(key)
+        m = int(count.item())
+        if m > 0:
+            dict.__setitem__(self, key, per_ray[:m].unsqueeze(-1).detach())
+
+    def materialise(self):
+        for key in list(self.lazy):
+            self._materialise(key)
+        return self
+
+    def present(self):
+        """(key, value) pairs already in the dict; pending lazy entries are left alone (no device-to-host read)."""
+        return dict.items(self)
+
+    def __missing__(self, key):
+        if key in self.lazy:
+            self._materialise(key)
+            if dict.__contains__(self, key):
+                return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        if key in self.lazy:
+            self._materialise(key)
+        return dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __iter__(self):
+        return dict.__iter__(self.materialise())
+
+    def __len__(self):
+        return dict.__len__(self.materialise())
+
+    def keys(self):
+        return dict.keys(self.materialise())
+
+    def items(self):
+        return dict.items(self.materialise())
+
+    def values(self):
+        return dict.values(self.materialise())
+
+    def copy(self):
+        return dict(dict.items(self.materialise()))

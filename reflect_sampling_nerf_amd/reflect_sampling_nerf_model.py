@@ -3,9 +3,9 @@
 
 get_outputs (reference model.py:142-344) becomes a fixed sequence of asynchronous kernel launches on the
 current stream -- samplers, the fused field kernel, per-ray compositing, device-side stable compaction of
-the reflected rays (dynamic M read from device memory by the later launches) -- with ONE host sync at
-the very end (reading M to shape `depth_reflect_fine`).  The reference's debug prints / six syncs
-(model.py:230,263-265,342) are not reproduced.
+the reflected rays (dynamic M read from device memory by the later launches) -- with NO host sync: the one
+output whose SHAPE depends on M (`depth_reflect_fine`, [M, 1]) is materialised on first use (ops.LazyOutputs).
+The reference's debug prints / six syncs (model.py:230,263-265,342) are not reproduced.
 """
 from __future__ import annotations
 
@@ -122,7 +122,7 @@ class ReflectSamplingNeRFModel(Model):
         aux = self._train_aux
         self._train_aux = None
         outputs = type(aux)(zip(DIFF_KEYS, outs))  # LazyOutputs: depth_reflect_fine ([M, 1]) on first access
-        for k, v in aux.items():
+        for k, v in aux.present():  # (not items(): that would materialise the lazy [M, 1] entry -- a host read)
             outputs[k] = v.detach() if v.dtype.is_floating_point else v
         outputs.lazy = aux.lazy
         # not keys of the reference's dict: the normal losses of get_loss_dict, reduced per ray by the compositing kernel
@@ -163,7 +163,7 @@ class ReflectSamplingNeRFModel(Model):
         rs = ops.reflect_setup(o, d, cf["accumulation"], cf["depth"], cf["normals"], cf["roughness"], float(self.far))
         n_dev = rs["n_masked"]
 
-        outputs = {
+        outputs = ops.LazyOutputs({
             "mid_rgb_coarse": cc["rgb"],
             "mid_rgb_fine": cf["rgb"],
             "mid_reflect_coarse": rs["reflect_coarse"],
@@ -184,7 +184,7 @@ class ReflectSamplingNeRFModel(Model):
             "tint": cf["tint"],
             "roughness": cf["roughness"].unsqueeze(-1),
             "mask": rs["mask"].bool(),
-        }
+        })
 
         # E-G. reflected rays; every launch below reads M from device memory (no host sync)
         o2, d2, pa2, near2, far2 = rs["origins2"], rs["directions2"], rs["pixel_area2"], rs["nears2"], rs["fars2"]
@@ -200,10 +200,39 @@ class ReflectSamplingNeRFModel(Model):
         crf = ops.composite(R, n_dev, Srf, 2, EVAL, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
         ops.reflect_combine(R, n_dev, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
 
-        M = int(n_dev.item())  # the only host sync: shapes depth_reflect_fine like the reference's [M,1]
-        if M > 0:
-            outputs["depth_reflect_fine"] = crf["depth"][:M].unsqueeze(-1)
+        # depth_reflect_fine is [M, 1] and present only when M > 0 (model.py:341): M stays on the device and the entry is
+        # materialised on first use (ops.LazyOutputs) -- get_outputs itself issues no device-to-host read, so a chunked
+        # image render enqueues every chunk before anything waits
+        outputs.lazy["depth_reflect_fine"] = (n_dev, crf["depth"])
         return outputs
+
+    # ------------------------------------------------------------------ eval image, chunked (config.py:41; "next" row §8(f).4)
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle) -> Dict[str, Tensor]:
+        """Chunked full-image rendering: `eval_num_rays_per_chunk` rays per forward (reference config.py:41: 1024),
+        per-ray outputs concatenated and reshaped to the image -- what nerfstudio's base Model does, overridden here
+        (for nerfstudio's own base class too) so that EVERY CHUNK IS ENQUEUED BEFORE ANYTHING IS READ BACK: get_outputs
+        issues no device-to-host read (the one output whose shape needs the reflected-ray count, depth_reflect_fine
+        [M, 1], is lazy and is no image anyway; the base class's `.items()` would materialise it once per chunk), so the
+        GPU runs chunk after chunk while the host is already launching the following ones."""
+        chunk = self.config.eval_num_rays_per_chunk
+        image_shape = camera_ray_bundle.origins.shape[:-1]
+        n = 1
+        for s_ in image_shape:
+            n *= int(s_)
+        lists: Dict[str, list] = {}
+        n_chunks = 0
+        for i in range(0, n, chunk):
+            rb = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, min(i + chunk, n))
+            n_chunks += 1
+            out = self.forward(rb)
+            present = out.present() if hasattr(out, "present") else out.items()
+            for k, v in present:
+                if isinstance(v, Tensor) and v.shape[:1] == (len(rb),):
+                    lists.setdefault(k, []).append(v)
+        # per-ray outputs only: a key that is not [rays, ...] in every chunk (depth_reflect_fine is [M,1]) is no image
+        return {k: torch.cat(v).view(*image_shape, *v[0].shape[1:]) for k, v in lists.items()
+                if len(v) == n_chunks and k != "depth_reflect_fine"}
 
     # ------------------------------------------------------------------ loss (model.py:346-430; "next" row §8(f).1)
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:

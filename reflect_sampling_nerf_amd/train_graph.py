@@ -328,44 +328,7 @@ def _ray_sum(x: Tensor, n: int, S: int, n_dev=None) -> Tensor:
     return out
 
 
-class LazyOutputs(dict):
-    """The output dict of a training-mode get_outputs.  One key of the reference needs the reflected-ray count M on the
-    host: `depth_reflect_fine`, [M, 1], present only when M > 0 (model.py:341).  Here M lives on the device for the whole
-    step, so that entry is materialised on FIRST ACCESS (`d["depth_reflect_fine"]`, `"depth_reflect_fine" in d`,
-    `d.get(...)`, `d.materialise()`): one device-to-host read then, none for a training step that never looks at it
-    (get_loss_dict does not).  `keys()` / `items()` list it once it has been materialised."""
-
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self.lazy: Dict[str, tuple] = {}
-        self.fused: Optional[Dict[str, Tensor]] = None  # FUSED_KEYS tensors for get_loss_dict (set by the model)
-
-    def _materialise(self, key):
-        count, per_ray = self.lazy.pop(key)
-        m = int(count.item())
-        if m > 0:
-            dict.__setitem__(self, key, per_ray[:m].unsqueeze(-1).detach())
-
-    def materialise(self):
-        for key in list(self.lazy):
-            self._materialise(key)
-        return self
-
-    def __missing__(self, key):
-        if key in self.lazy:
-            self._materialise(key)
-            if dict.__contains__(self, key):
-                return dict.__getitem__(self, key)
-        raise KeyError(key)
-
-    def __contains__(self, key):
-        if key in self.lazy:
-            self._materialise(key)
-        return dict.__contains__(self, key)
-
-    def get(self, key, default=None):
-        return self[key] if key in self else default
-
+from .ops import LazyOutputs  # noqa: E402,F401  (kept importable from here)
 
 _LazyAux = LazyOutputs
 

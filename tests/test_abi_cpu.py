@@ -171,3 +171,18 @@ def test_diagnostic_macros_cannot_enter_the_product_library(tmp_path):
     bad = subprocess.run(base + ["-DRSN_R16_NO_MFMA"], capture_output=True, text=True)
     assert bad.returncode != 0 and "RSN_DIAG_BUILD" in bad.stderr
     assert subprocess.run(base + ["-DRSN_R16_NO_MFMA", "-DRSN_DIAG_BUILD"], capture_output=True).returncode == 0
+
+
+def test_product_library_reads_no_environment_switches():
+    """The product librsn_hip.so takes no run-time A/B switches from the environment (RSN_BF16_PER_WAVE_STREAM,
+    RSN_RING_STAGGER, RSN_RING_WAVES, RSN_RING_SHAPE32 were read by getenv in the product path): those names, and getenv
+    itself, exist in diagnostic builds only (-DRSN_DIAG_BUILD); the 32x32x16 A/B ring kernel is not in the code object."""
+    import subprocess
+
+    path = _abi.library_path() if hasattr(_abi, "library_path") else os.path.join(REPO, "reflect_sampling_nerf_amd", "librsn_hip.so")
+    blob = open(path, "rb").read()
+    for name in (b"RSN_RING_STAGGER", b"RSN_RING_WAVES", b"RSN_RING_SHAPE32", b"RSN_BF16_PER_WAVE_STREAM", b"RSN_RING_", b"RSN_BF16_"):
+        assert name not in blob, name
+    nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True)
+    assert nm.returncode == 0 and "getenv" not in nm.stdout
+    assert b"rsn_field_bf16_ring_kernel" not in blob and b"rsn_field_bf16_ring16_kernel" in blob

@@ -732,6 +732,44 @@ def test_camera_ray_bundle_chunked_eval(dev):
                                                     depth_panel(c["depth_fine"], c["accumulation_fine"])], dim=1)) <= 1e-6
 
 
+def test_chunked_eval_image_issues_no_device_to_host_read(dev):
+    """The eval-image path (reference config.py:41: chunks of 1024 rays through Model.forward) enqueues EVERY chunk
+    before anything is read back: eval-mode get_outputs keeps the reflected-ray count on the device and its one
+    M-shaped output (depth_reflect_fine, model.py:341) lazy.  torch's sync-debug mode turns any implicit
+    device-to-host synchronisation into an error.  Afterwards the lazy entry of a single forward still has the
+    reference's shape and the dict lists the reference's keys, and the chunked image equals the one-chunk image."""
+    torch.manual_seed(4)
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=16, num_importance_samples=16,
+                                            num_reflect_coarse_samples=8, num_reflect_importance_samples=8,
+                                            base_mlp_num_layers=4, base_mlp_layer_width=64, eval_num_rays_per_chunk=64)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 1.5
+    model.to(dev).eval()
+    H, Wd = 10, 33
+    n = H * Wd
+    o, d, pa = cpu_ref.synthetic_rays(n, seed=12)
+    rb = pkg.RayBundle(origins=o.reshape(H, Wd, 3).to(dev), directions=d.reshape(H, Wd, 3).to(dev),
+                       pixel_area=pa.reshape(H, Wd, 1).to(dev))
+    flat = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.reshape(n, 1).to(dev))
+    model(flat)  # warm-up: one-time uploads (packed weights)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        img = model.get_outputs_for_camera_ray_bundle(rb)  # 6 chunks (330 = 5 x 64 + 10)
+        single = model(flat)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    M = int(single["mask"].sum())
+    assert 0 < M < n
+    assert "depth_reflect_fine" in single.keys() and single["depth_reflect_fine"].shape == (M, 1)
+    assert len(single) == 21 and "depth_reflect_fine" not in img
+    for k in ("mid_rgb_fine", "mid_reflect_fine", "accumulation_fine", "depth_fine", "diff", "tint", "roughness"):
+        assert img[k].shape[:2] == (H, Wd)
+        assert torch.equal(img[k].reshape(n, -1), single[k].reshape(n, -1)), k  # rays are independent: bit-identical
+    assert torch.equal(img["mask"].reshape(n), single["mask"])
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16"])
 @pytest.mark.parametrize("layers,width", [(8, 256), (4, 128), (6, 64)])
 def test_single_launch_packing_equals_per_segment_packing(dev, layers, width, mode):
@@ -1019,6 +1057,43 @@ def test_weight_grad_jobs_equal_separate_launches(dev, monkeypatch, mode, n_jobs
             assert float(dw[:, :c0].abs().max()) == 0.0
         if db is not None:
             assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+
+
+@pytest.mark.parametrize("path", ["f32", "bf16", "bf16x6", "jobs"])
+@pytest.mark.parametrize("n_out,k_in", [(3, 128), (16, 256), (250, 99), (250, 256), (37, 130)])
+def test_weight_grad_flush_stays_inside_its_rows(dev, monkeypatch, path, n_out, k_in):
+    """The weight-gradient flush adds a 32-row (64-row) register tile into dW by buffer atomics; rows >= n_out of the tile
+    hold clamped duplicates of live rows and MUST be dropped.  In the training step dW is a view into the flat gradient
+    buffer (train_graph._GradAcc), so a missed drop would land in the next parameter's gradient.  Here dW is the first
+    n_out rows of a larger zero buffer: the rows behind it must stay exactly 0 (reference: autograd writes a Linear's
+    weight gradient into that parameter only, reflect_sampling_nerf_field.py:54-86)."""
+    from reflect_sampling_nerf_amd import train_graph
+
+    g = torch.Generator().manual_seed(5 * n_out + k_in)
+    lens = [1000, 37, 2051]
+    segs, ref_w = [], torch.zeros(n_out, k_in, dtype=torch.float64)
+    ld_dy = n_out + (n_out & 1) if n_out > 32 else (16 if n_out > 4 else 4)
+    for n in lens:
+        dy, x = torch.randn(n, ld_dy, generator=g) + 0.5, torch.randn(n, k_in, generator=g) + 0.5
+        ref_w += dy[:, :n_out].double().t() @ x.double()
+        segs.append((dy.to(dev), x.to(dev)))
+    rows_total = n_out + 70  # more than one register tile of rows behind the live ones
+    big = torch.zeros(rows_total, k_in, device=dev)
+    bias_big = torch.zeros(rows_total, device=dev)
+    dw, db = big[:n_out], bias_big[:n_out]
+    monkeypatch.setattr(train_graph, "_WGRAD_MODE", {"f32": 0, "bf16": 3, "bf16x6": 1, "jobs": 0}[path])
+    if path == "jobs":
+        big2 = torch.zeros(rows_total, k_in, device=dev)
+        train_graph._wgrad_jobs([(segs, dw, 0, db), (segs, big2[:n_out], 0, None)], n_out, k_in)
+        assert float(big2[n_out:].abs().max()) == 0.0
+        assert float((big2[:n_out].double().cpu() - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max())
+    else:
+        train_graph._wgrad_multi(segs, n_out, k_in, dw, 0, db)
+    tol = 2e-2 if path == "bf16" else 2e-5
+    assert float((dw.double().cpu() - ref_w).abs().max()) <= tol * float(ref_w.abs().max())
+    assert float(big[n_out:].abs().max()) == 0.0, "the flush wrote behind the n_out live rows of dW"
+    assert float(bias_big[n_out:].abs().max()) == 0.0
+
 
 
 def test_standalone_sh34_encoding_matches_reference_golden(dev):
