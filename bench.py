@@ -65,6 +65,37 @@ def algorithmic_macs(layers: int, width: int):
             "backward_input": bwd + ENC_DIM * W * (2 if skip else 1), "wgrad": fwd}
 
 
+def collective_config(dist, backend, world):
+    """The `config` entries that describe the data-parallel layout of a run (the driver checks `rccl_ranks` against N)."""
+    return {
+        "parallelism": "dp%d" % world,
+        "collective": None if dist is None else "all-reduce(sum)/N of one flat fp32 gradient buffer per step",
+        "rccl_ranks": int(dist.get_world_size()) if (dist is not None and backend == "nccl") else 0,
+        "backend": backend,
+    }
+
+
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT initialising HIP in the launcher (torch.cuda.device_count() falls through to
+    hipGetDeviceCount on a build without amdsmi): the visible-devices environment if set, else the KFD topology (nodes
+    with a gfx target are GPUs).  None if neither is available -- the ranks then report a shortfall themselves."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as fh:
+                props = dict(line.split(None, 1) for line in fh if " " in line)
+            if int(props.get("gfx_target_version", "0")) != 0:
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +106,7 @@ def parse():
     ap.add_argument("--coarse", type=int, default=0, help="coarse samples if different from --samples (configs[2]: 64)")
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--width", type=int, default=256)
-    ap.add_argument("--workload", default="train", choices=["train", "level", "get_outputs", "selftest"],
+    ap.add_argument("--workload", default="train", choices=["train", "level", "get_outputs", "eval_image", "selftest"],
                     help="train = the BASELINE metric (default): full optimisation step; level = BASELINE configs[1], "
                          "fused forward + composite of one sampling level (eval); get_outputs = full eval get_outputs; "
                          "selftest = launch plumbing only (process group over gloo on the CPU, no GPU work)")
@@ -420,6 +451,48 @@ def run_get_outputs(pkg, args, dev, steps, warmup, dog):
             "value": R * steps / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps}
 
 
+def run_eval_image(pkg, args, dev, dog, side=800, chunks=(1024, 4096, 16384), repeats=2):
+    """The eval-image path: a side x side image of camera rays through
+    Model.get_outputs_for_camera_ray_bundle, `eval_num_rays_per_chunk` rays per forward -- the reference's 1024
+    (config.py:41) and two larger chunk sizes -- full eval get_outputs per chunk (128 + 128 + reflect 64 + 64).  Every
+    chunk is enqueued before anything is read back (no device-to-host read per chunk); rays/s = image rays / wall time
+    of the whole image, best of `repeats`."""
+    from reflect_sampling_nerf_amd.synthetic import synthetic_rays
+
+    torch.manual_seed(0)
+    n = side * side
+    o, d, pa = synthetic_rays(n, seed=3)
+    rb = pkg.RayBundle(origins=o.reshape(side, side, 3).to(dev), directions=d.reshape(side, side, 3).to(dev),
+                       pixel_area=pa.reshape(side, side, 1).to(dev))
+    out = {"workload": "eval image: %d x %d camera rays through get_outputs_for_camera_ray_bundle (full eval get_outputs per "
+                       "chunk: 128 + 128 + reflect 64 + 64 samples, %dx%d field, %s), no host read per chunk"
+                       % (side, side, args.layers, args.width, args.mma), "unit": "rays/s", "chunks": {}}
+    for chunk in chunks:
+        cfg = pkg.ReflectSamplingNeRFModelConfig(base_mlp_num_layers=args.layers, base_mlp_layer_width=args.width,
+                                                eval_num_rays_per_chunk=chunk)
+        model = cfg.setup(scene_box=None, num_train_data=1)
+        with torch.no_grad():
+            model.field.field_output_density.net.bias += 2.0
+        model.to(dev).eval()
+        model.field.set_mma_mode(args.mma)
+        best = None
+        for rep in range(repeats + 1):  # the first pass warms the allocator up and is not counted
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = model.get_outputs_for_camera_ray_bundle(rb)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if rep >= 1:
+                best = dt if best is None else min(best, dt)
+            dog.beat()
+        out["chunks"][str(chunk)] = {"rays_per_s": n / best, "ms_per_image": best * 1e3,
+                                     "reflect_ray_fraction": float(img["mask"].float().mean())}
+        del model, img
+    out["value"] = out["chunks"][str(chunks[0])]["rays_per_s"]
+    out["ratio_first_to_4096"] = out["chunks"][str(chunks[0])]["rays_per_s"] / out["chunks"].get("4096", out["chunks"][str(chunks[0])])["rays_per_s"]
+    return out
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -512,8 +585,8 @@ def main():
         # the driver's command shape: no launcher.  Start the ranks as fresh children BEFORE anything here touches the
         # GPU (never re-exec a process that initialised HIP) and exit with the worst child code.
         if args.workload != "selftest" and os.environ.get("RSN_BENCH_SHARE_GPU") != "1":
-            have = torch.cuda.device_count()  # does not initialise the GPU
-            if have < args.gpus:
+            have = visible_gpu_count()  # sysfs / environment only: the launcher never initialises HIP
+            if have is not None and have < args.gpus:
                 sys.stderr.write(json.dumps({"error": "bench.py --gpus %d: %d GPU(s) visible (RSN_BENCH_SHARE_GPU=1 "
                                                       "rehearses N ranks on one GPU over gloo)" % (args.gpus, have)}) + "\n")
                 sys.exit(2)
@@ -574,10 +647,7 @@ def main():
                                        ("ONE flat 618513-float gradient all-reduce (%s, %d ranks)" % (backend, world))
                                        if dist is not None else "no collective (N=1)", rec["reflect_ray_fraction"]),
                         "rays_per_gpu": R, "samples_per_ray": S, "global_rays_per_step": world * R,
-                        "parallelism": "dp%d" % world,
-                        "collective": None if dist is None else "all-reduce(sum)/N of one flat fp32 gradient buffer per step",
-                        "rccl_ranks": dist.get_world_size() if (dist is not None and backend == "nccl") else 0,
-                        "backend": backend,
+                        **collective_config(dist, backend, world),
                         "weights": "random-init (nn.Linear default), seed 0, density bias +2",
                     },
                     "roofline": {
@@ -606,6 +676,7 @@ def main():
                 bf = run_train(pkg, bf_args, dev, rank, world, None, share, samples, min(args.steps, 10),
                                min(max(args.warmup, 1), 3), dog, time_kernels=False)
                 line["eval_level"] = lv
+                line["eval_image"] = run_eval_image(pkg, args, dev, dog)
                 line["train_step_bf16_sweeps"] = {
                     "workload": "the headline step in REDUCED precision (opt-in; the reference itself trains under fp16 "
                                 "autocast, config.py:33): forward / backward sweeps with plain bf16 MFMA operands and fp32 "
@@ -626,11 +697,16 @@ def main():
                     line["eval_level"]["cpu_baseline"] = cpu_baseline_level(args)
         else:
             assert world == 1, "--workload level / get_outputs are single-GPU measurements"
-            rec = run_level(pkg, args, dev, args.steps, args.warmup, dog) if args.workload == "level" else \
-                run_get_outputs(pkg, args, dev, args.steps, args.warmup, dog)
+            if args.workload == "eval_image":
+                rec = run_eval_image(pkg, args, dev, dog)
+                rec["ms_per_step"] = rec["chunks"]["1024"]["ms_per_image"]
+            else:
+                rec = run_level(pkg, args, dev, args.steps, args.warmup, dog) if args.workload == "level" else \
+                    run_get_outputs(pkg, args, dev, args.steps, args.warmup, dog)
             line = {
                 "metric": "rays/sec (%s) at %d rays x %d samples, 1 MI355X" %
-                          ("eval forward + composite of one level" if args.workload == "level" else "eval get_outputs", R, S),
+                          ("eval forward + composite of one level" if args.workload == "level" else
+                           "eval image, 800 x 800, chunks of 1024 rays" if args.workload == "eval_image" else "eval get_outputs", R, S),
                 "value": rec["value"], "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": {"f32": "f32", "bf16x6": "f32 (emulated: 3-way bf16 split, 6 bf16 MFMA products, f32 accumulate)",
@@ -642,6 +718,8 @@ def main():
             }
             if "roofline" in rec:
                 line["roofline"] = rec["roofline"]
+            if "chunks" in rec:
+                line["eval_image"] = rec
             if args.workload == "level" and not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline_level(args)
     except BaseException:

@@ -105,3 +105,47 @@ def test_main_takes_the_self_launch_branch_without_world_size(monkeypatch):
     monkeypatch.setattr(bench, "run_selftest", lambda rank, world: calls.append(("rank", rank, world)))
     bench.main()
     assert calls == [("rank", 0, 2)]
+
+
+def _load_bench():
+    sys.path.insert(0, REPO)
+    import bench
+
+    return bench
+
+
+def test_json_line_reports_rccl_ranks_for_the_nccl_backend():
+    """The driver checks `config.rccl_ranks == N` on the N > 1 lines: it must be the process group's size whenever the
+    backend is RCCL ("nccl" on ROCm), and 0 for the gloo rehearsal / a run without a collective."""
+    bench = _load_bench()
+
+    class FakeDist:
+        def __init__(self, n):
+            self.n = n
+
+        def get_world_size(self):
+            return self.n
+
+    for n in (2, 4, 8):
+        cfg = bench.collective_config(FakeDist(n), "nccl", n)
+        assert cfg["rccl_ranks"] == n and cfg["parallelism"] == "dp%d" % n and cfg["backend"] == "nccl"
+        assert "all-reduce" in cfg["collective"]
+    assert bench.collective_config(FakeDist(2), "gloo", 2)["rccl_ranks"] == 0
+    assert bench.collective_config(None, None, 1) == {"parallelism": "dp1", "collective": None, "rccl_ranks": 0, "backend": None}
+
+
+def test_launcher_counts_gpus_without_initialising_hip(monkeypatch):
+    """The self-launching parent must not touch HIP before it forks the ranks: the GPU count comes from the
+    visible-devices environment or the KFD topology in sysfs, never from torch.cuda / hipGetDeviceCount."""
+    bench = _load_bench()
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    n = bench.visible_gpu_count()  # this container has no /dev/kfd: None (the ranks then report a shortfall themselves)
+    assert n is None or n >= 0
+    import inspect
+
+    src = inspect.getsource(bench.main)
+    assert "torch.cuda.device_count" not in src.split("self_launch(args.gpus")[0]

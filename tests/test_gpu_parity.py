@@ -242,12 +242,16 @@ def test_get_outputs_empty_mask_takes_early_out_shape(dev):
         assert max_abs(out[k].cpu(), ref[k]) <= TOL
 
 
-@pytest.mark.parametrize("name", ["eval_l8_w64_near0", "eval_l8_w256", "eval_l4_w128", "eval_l6_w64_nomask"])
+@pytest.mark.parametrize("name", ["eval_l8_w64_near0", "eval_l8_w256", "eval_l4_w128", "eval_l6_w64_nomask",
+                                  "eval_trained_l8_w64", "eval_trained_l8_w256"])
 def test_get_outputs_on_reference_golden_rays(dev, name):
     """Ties the GPU path to the REFERENCE run directly: the reference's own parameters (state_dict loaded by name), its
     rays, and ITS outputs (tests/golden/*.npz, written by oracle/make_golden.py from the reference's modules) -- at the
     BASELINE network (8 x 256), the configs[0] network (4 x 128), near plane 0 and the no-mask early-out
-    (model.py:259-260).  Rendered outputs within 1e-4, mask exact, early-out keys identical."""
+    (model.py:259-260) -- and on TRAINED weights (eval_trained_*: the reference trained on the procedural scene by
+    oracle/make_golden_trained.py until it left the initialisation regime: peaked densities, surface-concentrated
+    weights, a reflection mask decided by learned normals; config.py:32 trains for 100 000 iterations, that is the
+    regime the method runs in).  Rendered outputs within 1e-4, mask exact, early-out keys identical."""
     meta, g = load_golden(name)
     s = meta["samples"]
     torch.manual_seed(0)
@@ -1195,7 +1199,8 @@ def test_pdf_sampler_degenerate_histograms(dev, kind, tan, near, far):
         assert float(((eb.cpu() - eb_ref).abs() / (1.0 + eb_ref.abs())).max()) <= 2e-5
 
 
-@pytest.mark.parametrize("name", ["trainstep_l8_w64", "trainstep_l8_w256", "trainstep_l4_w128"])
+@pytest.mark.parametrize("name", ["trainstep_l8_w64", "trainstep_l8_w256", "trainstep_l4_w128",
+                                  "trainstep_trained_l8_w64", "trainstep_trained_l8_w256"])  # trained_*: TRAINED weights
 @pytest.mark.parametrize("inject_bins,mma", [(True, "f32"), (False, "f32"), (True, "bf16x6")])
 def test_train_step_against_reference_fixture(dev, name, inject_bins, mma):
     """One whole training step of the REFERENCE itself (tests/golden/trainstep_*.npz: get_outputs in train mode, its

@@ -10,8 +10,12 @@ from tests.helpers import field_spec_from_meta, load_golden, max_abs, model_spec
 
 CASES = ["eval_l8_w32", "train_l8_w32", "eval_l4_w32", "eval_l6_w32_nomask", "eval_l8_w64_near0",
          # shapes the HIP kernels run (tests/test_gpu_parity.py compares the HIP path with the same files directly)
-         "eval_l8_w256", "eval_l4_w128", "eval_l6_w64_nomask"]
-TRAIN_STEP_CASES = ["trainstep_l8_w64", "trainstep_l8_w256", "trainstep_l4_w128"]
+         "eval_l8_w256", "eval_l4_w128", "eval_l6_w64_nomask",
+         # TRAINED weights: the reference trained by oracle/make_golden_trained.py (its own get_outputs / get_loss_dict /
+         # RAdam on the procedural scene) until it left the initialisation regime, then recorded
+         "eval_trained_l8_w64", "eval_trained_l8_w256"]
+TRAIN_STEP_CASES = ["trainstep_l8_w64", "trainstep_l8_w256", "trainstep_l4_w128",
+                    "trainstep_trained_l8_w64", "trainstep_trained_l8_w256"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -27,7 +31,10 @@ def test_get_outputs_matches_reference(name):
     # the sampler outputs the reference logged (forward hooks on its four samplers): same bin edges
     assert sorted(rec) == sorted(g["bins"])
     for k, v in g["bins"].items():
-        assert max_abs(rec[k], v) <= (2e-6 if k.endswith("spacing") or "reflect" not in k else 2e-5), k
+        if k.endswith("spacing") or "reflect" not in k:
+            assert max_abs(rec[k], v) <= 2e-6, k
+        else:  # euclidean bins of the reciprocal spacing reach 256: relative bound
+            assert float(((rec[k] - v).abs() / (1.0 + v.abs())).max()) <= 2e-5, k
     assert sorted(out.keys()) == sorted(ref.keys()) == meta["keys"]
     assert torch.equal(out["mask"].to(torch.uint8), ref["mask"])
     assert int(out["mask"].sum()) == meta["M"]
@@ -35,9 +42,12 @@ def test_get_outputs_matches_reference(name):
         if k == "mask":
             continue
         assert tuple(out[k].shape) == tuple(v.shape), k
+        if k.startswith("depth"):  # median depths: up to 256 along a reflected ray (reciprocal spacing): relative bound
+            err = float(((out[k].detach() - v).abs() / (1.0 + v.abs())).max())
+            assert err <= 1e-5, f"{name}:{k}: max rel err {err}"
+            continue
         err = max_abs(out[k].detach(), v)
-        tol = 2e-6 if not k.startswith("depth") else 1e-5
-        assert err <= tol, f"{name}:{k}: max abs err {err}"
+        assert err <= 2e-6, f"{name}:{k}: max abs err {err}"
 
 
 def test_nomask_case_takes_early_out():
