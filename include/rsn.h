@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 14
+#define RSN_ABI_VERSION 15
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -119,6 +119,18 @@ typedef struct rsn_field_saved {
 
 int rsn_abi_version(void);
 const char* rsn_last_error(void);
+
+/* Layout of the two NARROW saved buffers of a training forward, which depends on the kernel that serves the Field's shape and
+ * MMA mode (ABI 15).  Default (rsn_field_kernel): enc = fp32 [N,104], sh = fp32 [N,40] in that kernel's slot order.  With
+ * mma_mode == RSN_MMA_BF16 at width 256 the training forward / backward run on the LDS weight ring
+ * (rsn_field_bf16_train.hip): enc = bf16 [N,128], sh = bf16 [N,64], slot s = 32 kk + 8 g + e of lane group g, and the
+ * ReLU bit words of rsn_field_saved.relu_bits are laid out [L+1][N][4 lane groups][2 words].
+ * Outputs: *enc_cols / *sh_cols = row length in elements, *narrow_bf16 = 1 if enc / sh rows hold bf16; enc_map[s] / sh_map[s]
+ * (caller arrays of 128 / 64 ints, HOST) = column of the reference's 99-wide NeRFEncoding output / 34-wide SH encoding
+ * (nerfstudio N2; reflect_sampling_nerf_components.py:38-140) that slot s carries, -1 for padding: the col_map of the
+ * weight gradients of trunk layer 0 / the skip layer (rsn_weight_grad_jobs) and of mlp_mid's SH part. */
+int rsn_train_saved_layout(const rsn_field_desc* desc, int32_t* enc_cols, int32_t* sh_cols, int32_t* narrow_bf16,
+                           int32_t* enc_map, int32_t* sh_map);
 
 /* ---- weights: nn.Linear layout -> MFMA fragment order ---------------------------------------
  * The field kernels stream weights in the exact order the 32x32x2 f32 MFMA consumes them; this

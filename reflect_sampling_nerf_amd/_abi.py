@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 14
+RSN_ABI_VERSION = 15
 RSN_ABI_DIAG_FLAG = 0x10000  # rsn_abi_version() of a -DRSN_DIAG_BUILD library (csrc/rsn_common.h)
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
@@ -182,6 +182,8 @@ _SIGNATURES = {
     "rsn_reflect_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "rsn_reflect_setup": (C.c_int, [C.c_int32, C.c_float, C.POINTER(ReflectIO), C.c_void_p]),
     "rsn_reflect_combine": (C.c_int, [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "rsn_train_saved_layout": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

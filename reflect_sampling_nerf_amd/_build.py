@@ -17,7 +17,7 @@ REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(REPO, "build", "obj")
 LIB_PATH = os.path.join(PKG_DIR, "librsn_hip.so")
-SOURCES = ["rsn_pack.hip", "rsn_field.hip", "rsn_field_split.hip", "rsn_field_bf16.hip", "rsn_field_bwd.hip", "rsn_wgrad.hip", "rsn_render.hip", "rsn_train_ops.hip"]
+SOURCES = ["rsn_pack.hip", "rsn_field.hip", "rsn_field_split.hip", "rsn_field_bf16.hip", "rsn_field_bf16_train.hip", "rsn_field_bwd.hip", "rsn_wgrad.hip", "rsn_render.hip", "rsn_train_ops.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17"]
 # Per-file flags on top of FLAGS.  -amdgpu-mfma-vgpr-form: MFMA accumulators in architected VGPRs instead of AGPRs.  The
 # field kernels' layer epilogues read every accumulator (ReLU, mask bits, LDS hand-off, saved rows) and re-load it with

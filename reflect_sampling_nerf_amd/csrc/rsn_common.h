@@ -90,10 +90,22 @@ struct RsnPackedLayout {
   // (i = lane & 15, g = lane >> 4) holds W[16 b + i][feature(kk, g, e)], e = 0..7, of fragment (K-step kk, row block b)
   size_t q_stream;                    // 0 = absent
   int q_groups;
+  // ... and, directly behind it (group indices continue), the TRANSPOSED 16x32 fragments of the training sweeps
+  // (rsn_field_bf16_train.hip) in consumption order: (RGB head)^T 1 group, (mlp_mid x part)^T 4, [bottleneck; heads]^T 9,
+  // then for l = L-1 .. 1: (encoded-input part of the skip layer)^T 4 groups in front of l == skip, (x part of layer l)^T 8;
+  // last (layer 0)^T 4 groups.  The backward sweep walks all of it (without the two encoded-input pieces when no input
+  // gradient is wanted); the analytic-normal sweep of the training forward walks [t_g_trunk, t_g_end) behind the forward stream.
+  int t_g_begin, t_g_trunk, t_g_encskip, t_g_enc0, t_g_end;   // absolute group indices from q_stream; t_g_encskip = -1: no skip layer
   size_t total;                       // floats
 };
 #ifndef RSN_RING_GROUP_FRAGS
 #define RSN_RING_GROUP_FRAGS 16
 #endif
+#define RSN_RING_MAX_LAYERS 10   // trunk depth the ring kernels' LDS bias table is sized for
+// the plain-bf16 TRAINING kernels on the LDS weight ring (rsn_field_bf16_train.hip) serve this shape; every other shape /
+// mode trains on rsn_field_kernel<., true, .> / rsn_field_bwd_kernel
+inline bool rsn_ring_training(const rsn_field_desc* d) {
+  return d->mma_mode == RSN_MMA_BF16 && d->width == 256 && d->num_layers <= RSN_RING_MAX_LAYERS && RSN_RING_GROUP_FRAGS == 16;
+}
 
 int rsn_compute_layout(const rsn_field_desc* desc, RsnPackedLayout* L);

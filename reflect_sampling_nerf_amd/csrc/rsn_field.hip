@@ -18,6 +18,7 @@
 // reflect_sampling_nerf_components.py:52-140 and the nerfstudio primitives N1-N3, N6.
 #define RSN_FIELD_MAIN_TU
 #include "rsn_field_kernel.h"
+#include "rsn_field_bwd_common.h"
 
 #ifdef RSN_PHASE_TIMERS
 extern "C" int rsn_debug_phase_cycles(unsigned long long* out16, int reset) {
@@ -69,6 +70,11 @@ static int launch_field_jobs(const rsn_field_desc* d, FieldArgs* js, int n, void
     static_cast<FieldJob&>(one) = J.j[0];
     const long long g2 = n_tiles < 2LL * cus ? n_tiles : 2LL * cus;
     return rsn_launch_field_bf16(d->width, g2, st, one);
+  }
+  if (train && rsn_ring_training(d)) {  // plain-bf16 training at width 256: the LDS-ring kernels (256-point tiles)
+    long long t256 = 0;
+    for (int k = 0; k < J.n_jobs; ++k) t256 += ((long long)J.j[k].n_rays * J.j[k].S + 255) / 256;
+    return rsn_launch_field_bf16_train(t256, st, J);
   }
   if (mode == RSN_MMA_BF16X6 || (!train && mode == RSN_MMA_BF16X3)) {  // split-bf16 instantiations: rsn_field_split.hip
     rc = rsn_launch_field_split(d->width, train, mode == RSN_MMA_BF16X6 ? 1 : 2, grid, st, J);

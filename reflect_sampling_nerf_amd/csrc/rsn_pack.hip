@@ -175,9 +175,59 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
       L->q_groups = (64 * (d->skip_layer >= 1 ? 2 : 1) + (d->num_layers - 1) * 128 + 16 + 128 + 16 + 64 + 16) / 16;
       L->q_stream = off;
       off += (size_t)L->q_groups * 16 * blk;
+      // transposed fragments of the training sweeps, directly behind (see RsnPackedLayout)
+      int tg = L->q_groups;
+      L->t_g_begin = tg;
+      tg += 1 + 4 + 9;
+      L->t_g_trunk = tg;
+      L->t_g_encskip = -1;
+      for (int l = d->num_layers - 1; l >= 1; --l) {
+        if (l == d->skip_layer) { L->t_g_encskip = tg; tg += 4; }
+        tg += 8;
+      }
+      L->t_g_enc0 = tg;
+      tg += 4;
+      L->t_g_end = tg;
+      off += (size_t)(tg - L->q_groups) * 16 * blk;
     }
   }
   L->total = off;
+  return RSN_OK;
+}
+
+extern "C" int rsn_train_saved_layout(const rsn_field_desc* d, int32_t* enc_cols, int32_t* sh_cols, int32_t* narrow_bf16,
+                                      int32_t* enc_map, int32_t* sh_map) {
+  RSN_REQUIRE(d && enc_cols && sh_cols && narrow_bf16 && enc_map && sh_map, RSN_ERR_INVALID_ARGUMENT, "a pointer is NULL");
+  RsnPackedLayout L;
+  const int rc = rsn_compute_layout(d, &L);
+  if (rc != RSN_OK) return rc;
+  for (int s = 0; s < 128; ++s) enc_map[s] = -1;
+  for (int s = 0; s < 64; ++s) sh_map[s] = -1;
+  if (rsn_ring_training(d)) {  // slot s = 32 kk + 8 g + e of lane group g (rsn_field_bf16_train.hip; cols_enc16 / cols_sh16 below)
+    *enc_cols = 128; *sh_cols = 64; *narrow_bf16 = 1;
+    for (int s = 0; s < 128; ++s) {
+      const int kk = s >> 5, g = (s >> 3) & 3, e = s & 7, u = kk * 8 + e;
+      if (u < 12) enc_map[s] = (u / 4) * 16 + 4 * g + (u % 4);
+      else if (u < 24) enc_map[s] = 48 + ((u - 12) / 4) * 16 + 4 * g + ((u - 12) % 4);
+      else if (u < 27 && g == 0) enc_map[s] = 96 + (u - 24);
+    }
+    for (int s = 0; s < 64; ++s) {
+      const int kk = s >> 5, g = (s >> 3) & 3, e = s & 7, u = kk * 8 + e;
+      if (u < 9 && 9 * g + u < RSN_SH_DIM) sh_map[s] = 9 * g + u;
+    }
+    return RSN_OK;
+  }
+  *enc_cols = RSN_K_ENC_PAD; *sh_cols = RSN_K_SH_PAD; *narrow_bf16 = 0;
+  for (int k = 0; k < RSN_K_ENC_PAD; ++k) {  // slot k = it * 8 + 4 h + s of lane half h (cols_encoding / cols_sh below)
+    const int it = k >> 3, h = (k >> 2) & 1, s = k & 3, u = it * 4 + s;
+    if (u < 24) enc_map[k] = (u / 8) * 16 + 8 * h + (u % 8);
+    else if (u < 48) enc_map[k] = 48 + ((u - 24) / 8) * 16 + 8 * h + ((u - 24) % 8);
+    else if (u < 51 && h == 0) enc_map[k] = 96 + (u - 48);
+  }
+  for (int k = 0; k < RSN_K_SH_PAD; ++k) {
+    const int it = k >> 3, h = (k >> 2) & 1, s = k & 3, u = it * 4 + s;
+    if (u < 17) sh_map[k] = 17 * h + u;
+  }
   return RSN_OK;
 }
 
@@ -212,7 +262,13 @@ __device__ __forceinline__ void pack_elem(const PackJob& job, int e) {
     const int n = b * 16 + (lane & 15), k = kk * 32 + (lane >> 4) * 8 + el;
     const int rs = job.row_src[n], c = job.col[k];
     float v = 0.0f;
-    if (rs >= 0 && c >= 0) v = job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
+    if (job.transpose == 3) {  // transposed, the SOURCE tensor selected by k ([heads]^T)
+      const int cs = job.col_src[k];
+      if (rs >= 0 && c >= 0 && cs >= 0) v = job.src[cs][(size_t)c * job.ld[cs] + job.row_idx[n]];
+    } else if (rs >= 0 && c >= 0) {
+      v = job.transpose ? job.src[rs][(size_t)c * job.ld[rs] + job.row_idx[n]]
+                        : job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
+    }
     reinterpret_cast<__bf16*>(job.dst)[e] = (__bf16)v;
     return;
   }
@@ -594,14 +650,20 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   // ---------------- 16x32 bf16 fragment stream (rsn_field_bf16_ring16_kernel), straight from the nn.Linear tensors ------
   if (L.q_stream != 0) {
     int frag = 0;
-    // K order of an x-layer: slot (kk, g, e) <- previous layer's feature 32 kk + 16 (e / 4) + 4 g + e % 4: the eight
-    // values lane (m, g) holds of blocks 2kk, 2kk+1 after the previous GEMM (lane-local hand-off)
-    auto cols_x16 = [&](PackJob& jj, int K, int offset) {
-      for (int k = 0; k < K; ++k) {
-        const int kk = k >> 5, g = (k >> 3) & 3, e = k & 7;
-        jj.col[k] = (int16_t)(offset + 32 * kk + 16 * (e >> 2) + 4 * g + (e & 3));
+    // Output rows of every GEMM whose result feeds another GEMM are PERMUTED: packed row 16 b + 4 g + r (what lane group g
+    // holds in accumulator register r of block b after the MFMA) <- source row 32 (b / 2) + 8 g + 4 (b % 2) + r.  The eight
+    // values lane (m, g) holds of blocks 2kk, 2kk+1 are then the CONTIGUOUS features 32 kk + 8 g .. + 7: the K order of
+    // the next layer is the natural one (slot (kk, g, e) <- feature 32 kk + 8 g + e, lane-local hand-off as before), and a
+    // training kernel stores a lane's share of an activation row as ONE 16-byte piece per K-step (the four lanes of a
+    // point cover 64 contiguous bytes) instead of two 8-byte pieces 32 bytes apart.
+    auto rows_perm16 = [&](PackJob& jj, int n_rows, int src = 0) {
+      for (int n = 0; n < n_rows; ++n) {
+        const int b = n >> 4, i = n & 15;
+        jj.row_src[n] = (int16_t)src;
+        jj.row_idx[n] = (int16_t)(32 * (b >> 1) + 8 * (i >> 2) + 4 * (b & 1) + (i & 3));
       }
     };
+    auto cols_x16 = [&](PackJob& jj, int K, int offset) { cols_natural(jj, K, offset); };
     // encoded inputs: lane group g owns frequencies 4g..4g+3; its 32 slots u = 8 kk + e: 12 sin, 12 cos, 3 raw (g == 0)
     auto cols_enc16 = [&](PackJob& jj) {
       for (int k = 0; k < 128; ++k) {
@@ -627,16 +689,16 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       return launch(jj, st);
     };
     clear_job(j);
-    j.src[0] = p->trunk_w[0]; j.ld[0] = RSN_ENC_DIM; rows_natural(j, W); cols_enc16(j);
+    j.src[0] = p->trunk_w[0]; j.ld[0] = RSN_ENC_DIM; rows_perm16(j, W); cols_enc16(j);
     if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
     for (int l = 1; l < d->num_layers; ++l) {
       const int in_f = (l == d->skip_layer) ? RSN_ENC_DIM + W : W;
       clear_job(j);
-      j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_natural(j, W); cols_x16(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0);
+      j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_perm16(j, W); cols_x16(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0);
       if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
       if (l == d->skip_layer) {
         clear_job(j);
-        j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_natural(j, W); cols_enc16(j);
+        j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_perm16(j, W); cols_enc16(j);
         if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
       }
     }
@@ -646,13 +708,13 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     heads_rows(j, 0); cols_x16(j, W, 0);
     if ((rc = qpiece(j, 8, 2)) != RSN_OK) return rc;
     clear_job(j);
-    j.src[0] = p->bottleneck_w; j.ld[0] = W; rows_natural(j, W); cols_x16(j, W, 0);
+    j.src[0] = p->bottleneck_w; j.ld[0] = W; rows_perm16(j, W); cols_x16(j, W, 0);
     if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
     clear_job(j);
-    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_natural(j, d->mid_width); cols_sh16(j);
+    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_perm16(j, d->mid_width); cols_sh16(j);
     if ((rc = qpiece(j, 2, 8)) != RSN_OK) return rc;
     clear_job(j);
-    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_natural(j, d->mid_width); cols_x16(j, W, RSN_SH_DIM);
+    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_perm16(j, d->mid_width); cols_x16(j, W, RSN_SH_DIM);
     if ((rc = qpiece(j, 8, 8)) != RSN_OK) return rc;
     clear_job(j);  // RGB head: rows 4..6 of the first of four 16-row blocks (three of them zero: whole-group padding)
     j.src[0] = p->rgb_w; j.ld[0] = d->mid_width;
@@ -661,6 +723,70 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     if ((rc = qpiece(j, 4, 4)) != RSN_OK) return rc;
     RSN_REQUIRE(frag == L.q_groups * 16, RSN_ERR_INVALID_ARGUMENT, "16x32 stream: %d fragments, layout says %d groups",
                 frag, L.q_groups);
+    // ---- transposed pieces (training sweeps): packed ROW 16 b + 4 g + r <- input feature r16_feature (source COLUMN), packed
+    //      K natural <- output feature (source ROW); transpose = 1 (see above: row_idx selects the source column)
+    auto rowsT_perm16 = [&](PackJob& jj, int n_rows, int col_offset) {
+      for (int n = 0; n < n_rows; ++n) {
+        const int b = n >> 4, i = n & 15;
+        jj.row_src[n] = 0;
+        jj.row_idx[n] = (int16_t)(col_offset + 32 * (b >> 1) + 8 * (i >> 2) + 4 * (b & 1) + (i & 3));
+      }
+    };
+    // encoded-input slots as packed rows: row 16 b + 4 g + r = slot (kk = b / 2, g, e = 4 (b % 2) + r) of cols_enc16
+    auto rowsT_enc16 = [&](PackJob& jj) {
+      for (int n = 0; n < 128; ++n) {
+        const int b = n >> 4, g = (n >> 2) & 3, r = n & 3, kk = b >> 1, e = 4 * (b & 1) + r, u = kk * 8 + e;
+        int c = -1;
+        if (u < 12) c = (u / 4) * 16 + 4 * g + (u % 4);
+        else if (u < 24) c = 48 + ((u - 12) / 4) * 16 + 4 * g + ((u - 12) % 4);
+        else if (u < 27 && g == 0) c = 96 + (u - 24);
+        jj.row_src[n] = (int16_t)(c >= 0 ? 0 : -1);
+        jj.row_idx[n] = (int16_t)(c >= 0 ? c : 0);
+      }
+    };
+    clear_job(j);  // (RGB head)^T: rows = 128 hidden features; K-step 0 slot (g = 1, e = 0..2) = k 8..10 <- rgb row 0..2; K-step 1 zero
+    j.transpose = 1; j.src[0] = p->rgb_w; j.ld[0] = d->mid_width; rowsT_perm16(j, d->mid_width, 0);
+    for (int c = 0; c < 3; ++c) j.col[8 + c] = (int16_t)c;
+    if ((rc = qpiece(j, 2, 8)) != RSN_OK) return rc;
+    clear_job(j);  // (mlp_mid x part)^T: rows = W bottleneck features (source columns 34..), K = 128 hidden rows
+    j.transpose = 1; j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rowsT_perm16(j, W, RSN_SH_DIM); cols_natural(j, d->mid_width, 0);
+    if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
+    clear_job(j);  // [bottleneck]^T: rows = W embedding features, K = W bottleneck rows ...
+    j.transpose = 1; j.src[0] = p->bottleneck_w; j.ld[0] = W; rowsT_perm16(j, W, 0); cols_natural(j, W, 0);
+    if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
+    {  // ... + [heads]^T as a ninth K-step: slot (g, e < 4) = k 8 g + e <- heads row 4 g + e (0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint)
+      const float* hw[5] = {p->density_w, p->normals_w, p->diff_w, p->roughness_w, p->tint_w};
+      const int hbase[5] = {0, 1, 4, 8, 12};
+      const int hrows[5] = {1, 3, 3, 1, 3};
+      clear_job(j);
+      j.transpose = 3;
+      for (int t = 0; t < 5; ++t) { j.src[t] = hw[t]; j.ld[t] = W; }
+      rowsT_perm16(j, W, 0);
+      for (int t = 0; t < 5; ++t)
+        for (int c = 0; c < hrows[t]; ++c) {
+          const int hr = hbase[t] + c;  // heads row 4 g + e
+          j.col[8 * (hr >> 2) + (hr & 3)] = (int16_t)c;
+          j.col_src[8 * (hr >> 2) + (hr & 3)] = (int16_t)t;
+        }
+      if ((rc = qpiece(j, 1, 16)) != RSN_OK) return rc;
+    }
+    for (int l = d->num_layers - 1; l >= 1; --l) {
+      const int in_f = (l == d->skip_layer) ? RSN_ENC_DIM + W : W;
+      if (l == d->skip_layer) {
+        clear_job(j);
+        j.transpose = 1; j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rowsT_enc16(j); cols_natural(j, W, 0);
+        if ((rc = qpiece(j, 8, 8)) != RSN_OK) return rc;
+      }
+      clear_job(j);
+      j.transpose = 1; j.src[0] = p->trunk_w[l]; j.ld[0] = in_f;
+      rowsT_perm16(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0); cols_natural(j, W, 0);
+      if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
+    }
+    clear_job(j);
+    j.transpose = 1; j.src[0] = p->trunk_w[0]; j.ld[0] = RSN_ENC_DIM; rowsT_enc16(j); cols_natural(j, W, 0);
+    if ((rc = qpiece(j, 8, 8)) != RSN_OK) return rc;
+    RSN_REQUIRE(frag == L.t_g_end * 16, RSN_ERR_INVALID_ARGUMENT, "transposed 16x32 stream: %d fragments, layout says %d groups",
+                frag, L.t_g_end);
   }
 
   // ---------------- split-bf16 copies (RSN_MMA_BF16X6 / X3 / BF16) of every GEMM segment ----------------

@@ -286,13 +286,41 @@ class ReflectSamplingNeRFNerfField(Field):
         stream and activation memory), fp32 otherwise (include/rsn.h: rsn_field_saved)."""
         return torch.bfloat16 if int(self.mma_mode) == _abi.RSN_MMA_BF16 else torch.float32
 
+    def train_layout(self) -> Dict:
+        """Layout of the narrow saved buffers (encoded inputs, SH inputs) of a training forward for this Field's shape and
+        MMA mode, from the library (rsn_train_saved_layout, include/rsn.h): row lengths, dtype and the slot -> reference
+        column maps the weight gradients of trunk layer 0 / the skip layer / mlp_mid's SH part scatter by."""
+        key = (int(self.mma_mode), self.width, self.mlp_base.num_layers)
+        lay = getattr(self, "_train_layout", None)
+        if lay is None or lay["key"] != key:
+            lib = _abi.load_library()
+            desc = self.field_desc()
+            enc_cols, sh_cols, narrow = C.c_int32(), C.c_int32(), C.c_int32()
+            enc_map, sh_map = (C.c_int32 * 128)(), (C.c_int32 * 64)()
+            check(lib.rsn_train_saved_layout(C.byref(desc), C.byref(enc_cols), C.byref(sh_cols), C.byref(narrow), enc_map, sh_map))
+            lay = {"key": key, "enc_cols": enc_cols.value, "sh_cols": sh_cols.value,
+                   "narrow_dtype": torch.bfloat16 if narrow.value else torch.float32,
+                   "enc_map": list(enc_map)[: enc_cols.value], "sh_map": list(sh_map)[: sh_cols.value], "dev": {}}
+            self._train_layout = lay
+        return lay
+
+    def train_col_maps(self, dev):
+        """(enc_map, sh_map) of train_layout() as int32 device tensors (cached per device)."""
+        lay = self.train_layout()
+        if dev not in lay["dev"]:
+            lay["dev"][dev] = (torch.tensor(lay["enc_map"], dtype=torch.int32, device=dev),
+                               torch.tensor(lay["sh_map"], dtype=torch.int32, device=dev))
+        return lay["dev"][dev]
+
     def alloc_saved(self, N: int, dev) -> Dict[str, Tensor]:
         """The buffers a training-mode forward over N points fills (rsn_field_saved)."""
         W, L = self.width, self.mlp_base.num_layers
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         wd = self.wide_dtype()
-        return {"enc": f(N, 104), "act": torch.empty(L, N, W, device=dev, dtype=wd),
-                "bott": torch.empty(N, W, device=dev, dtype=wd), "sh": f(N, 40),
+        lay = self.train_layout()
+        nd = lay["narrow_dtype"]
+        return {"enc": torch.empty(N, lay["enc_cols"], device=dev, dtype=nd), "act": torch.empty(L, N, W, device=dev, dtype=wd),
+                "bott": torch.empty(N, W, device=dev, dtype=wd), "sh": torch.empty(N, lay["sh_cols"], device=dev, dtype=nd),
                 "hid": torch.empty(N, 128, device=dev, dtype=wd), "heads": f(N, 8),
                 "relu_bits": torch.empty(L + 1, N, 2, max(W // 64, 2), device=dev, dtype=torch.int32)}
 

@@ -9,6 +9,7 @@ The reference's debug prints / six syncs (model.py:230,263-265,342) are not repr
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Type
 
@@ -222,14 +223,35 @@ class ReflectSamplingNeRFModel(Model):
             n *= int(s_)
         lists: Dict[str, list] = {}
         n_chunks = 0
+        # Small chunks (the reference's 1024 rays) leave the GPU with ramps, tails and a dozen 10-us launches per 3 ms of field
+        # kernels: consecutive chunks are independent, so they alternate between two side streams and one chunk's small
+        # launches / last partial round of tiles run beside the other's field kernels.
+        dev = camera_ray_bundle.origins.device
+        side = None
+        if dev.type == "cuda" and n > chunk:
+            self.field.packed_weights()  # packed once, on the caller's stream, before the side streams read it
+            main = torch.cuda.current_stream(dev)
+            side = getattr(self, "_eval_streams", None)
+            if side is None or side[0].device != dev:
+                side = self._eval_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            for st in side:
+                st.wait_stream(main)
         for i in range(0, n, chunk):
             rb = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, min(i + chunk, n))
+            ctx = torch.cuda.stream(side[n_chunks % 2]) if side is not None else contextlib.nullcontext()
             n_chunks += 1
-            out = self.forward(rb)
+            with ctx:
+                out = self.forward(rb)
             present = out.present() if hasattr(out, "present") else out.items()
             for k, v in present:
                 if isinstance(v, Tensor) and v.shape[:1] == (len(rb),):
                     lists.setdefault(k, []).append(v)
+        if side is not None:
+            for st in side:
+                main.wait_stream(st)
+            for vs in lists.values():  # allocated on a side stream, read by the caller's stream from here on
+                for v in vs:
+                    v.record_stream(main)
         # per-ray outputs only: a key that is not [rays, ...] in every chunk (depth_reflect_fine is [M,1]) is no image
         return {k: torch.cat(v).view(*image_shape, *v[0].shape[1:]) for k, v in lists.items()
                 if len(v) == n_chunks and k != "depth_reflect_fine"}

@@ -124,9 +124,8 @@ class _GradAcc:
         self.g: Dict[str, Tensor] = {n: v.view_as(p) for (n, p), v in zip(named, views)}
         self.heads_w = views[-2].view(16, W)  # rows: 0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint
         self.heads_b = views[-1]
-        if not hasattr(field, "_enc_col_map") or field._enc_col_map.device != dev:
-            field._enc_col_map = torch.tensor(enc_slot_columns(), dtype=torch.int32, device=dev)
-            field._sh_col_map = torch.tensor(sh_slot_columns(), dtype=torch.int32, device=dev)
+        # slot -> reference column of the saved encoded / SH inputs: the layout of the kernel that serves this shape and mode
+        field._enc_col_map, field._sh_col_map = field.train_col_maps(dev)
 
     def finish(self) -> Dict[str, Tensor]:
         dst, src = [], []
@@ -250,10 +249,10 @@ def _weight_grads(field, levels, acc: _GradAcc):
             ww.append((segs(lambda sv, go: (go["dy"][l], sv["act"][l - 1])), gw, 0, gb))
     ww.append((segs(lambda sv, go: (go["d_bott"], sv["act"][L - 1])), g["field_output_bottleneck.net.weight"], 0,
                g["field_output_bottleneck.net.bias"]))
-    _wgrad_jobs(we, W, ENC_SLOTS)
+    _wgrad_jobs(we, W, int(enc_map.numel()))
     for i in range(0, len(ww), _WGRAD_JOBS_MAX):
         _wgrad_jobs(ww[i:i + _WGRAD_JOBS_MAX], W, W)
-    _wgrad_multi(segs(lambda sv, go: (go["da_mid"], sv["sh"])), 128, SH_SLOTS, g["mlp_mid.layers.0.weight"], 0,
+    _wgrad_multi(segs(lambda sv, go: (go["da_mid"], sv["sh"])), 128, int(sh_map.numel()), g["mlp_mid.layers.0.weight"], 0,
                  g["mlp_mid.layers.0.bias"], sh_map)
     _wgrad_multi(segs(lambda sv, go: (go["da_mid"], sv["bott"])), 128, W, g["mlp_mid.layers.0.weight"], 34, None)
     _wgrad_multi(segs(lambda sv, go: (go["dz_rgb"], sv["hid"])), 3, 128, g["field_output_mid.net.weight"], 0,

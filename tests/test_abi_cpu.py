@@ -114,6 +114,19 @@ def test_slot_maps_are_permutations_of_the_reference_columns():
     assert len(enc) == ENC_SLOTS == 104 and sorted(c for c in enc if c >= 0) == list(range(99))
     sh = sh_slot_columns()
     assert len(sh) == SH_SLOTS == 40 and sorted(c for c in sh if c >= 0) == list(range(34))
+    # the library's own statement of the layout (rsn_train_saved_layout, ABI 15): the default kernels' slot order equals the host
+    # tables above; the plain-bf16 ring kernels (width 256) keep bf16 rows of 128 / 64 slots -- again every reference column once
+    torch = pytest.importorskip("torch")
+    for mode, width, want in (("f32", 256, (104, 40, torch.float32)), ("bf16", 128, (104, 40, torch.float32)),
+                              ("bf16", 256, (128, 64, torch.bfloat16))):
+        f = pkg.ReflectSamplingNeRFNerfField(base_mlp_num_layers=8, base_mlp_layer_width=width)
+        f.set_mma_mode(mode)
+        lay = f.train_layout()
+        assert (lay["enc_cols"], lay["sh_cols"], lay["narrow_dtype"]) == want
+        assert sorted(c for c in lay["enc_map"] if c >= 0) == list(range(99)) and len(lay["enc_map"]) == want[0]
+        assert sorted(c for c in lay["sh_map"] if c >= 0) == list(range(34)) and len(lay["sh_map"]) == want[1]
+        if want[0] == 104:
+            assert lay["enc_map"] == enc and lay["sh_map"] == sh
 
 
 def test_config_defaults_match_the_reference_run():
