@@ -48,6 +48,7 @@ if REPO not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
+HBM_PEAK_TBPS = 8.0  # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s measured for a float4 copy)
 ENC_DIM, SH_DIM, MID_W = 99, 34, 128
 
 
@@ -324,10 +325,28 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
             "wgrad": 2.0 * macs["wgrad"] * n_bwd,
         }
         kern = {}
+        ring = args.mma == "bf16" and args.width == 256  # plain-bf16 training at width 256: the LDS-ring kernels
+        mi = {"bf16x6": 1, "bf16": 3}.get(args.mma, 0)
+        # plain-bf16 mode: the saved rows ARE the traffic (256 FLOP per byte of row: as much HBM- as MFMA-bound).  Algorithmic HBM
+        # bytes per field point: forward writes L act rows + bottleneck (W bf16 each), mid hidden, encoded / SH inputs, raw heads,
+        # ReLU bits and the 64 B of per-sample outputs (+ 12 B of normals on the primary levels); the backward sweep writes L + 1
+        # wide gradient rows, d a_mid and the narrow head gradients and reads bits / heads / outputs (+ the encoded inputs where the
+        # gradient reaches them); the weight gradients read every row once (the encoded inputs twice: layer 0 and the skip layer).
+        Lw, Ww = args.layers, args.width
+        row_b = 2 if args.mma == "bf16" else 4
+        enc_b, sh_b = (256, 128) if ring else (416, 160)
+        skipw = Lw > 5
+        fwd_w = row_b * (Lw * Ww + Ww + MID_W) + enc_b + sh_b + 32 + 32 * (Lw + 1) + 64
+        bwd_w = row_b * (Lw * Ww + Ww + MID_W) + 64 + 16
+        bwd_r = 32 * (Lw + 1) + 32 + 64
+        wg_r = row_b * (2 * Lw * Ww + 2 * Ww + 2 * MID_W) + enc_b * (2 if skipw else 1) + sh_b + 64 + 16
+        hbm = {"forward": fwd_w * n_fwd + 12.0 * pts("field_forward_train_normals"),
+               "backward": (bwd_w + bwd_r) * n_bwd + enc_b * pts("field_backward_input"),
+               "wgrad": wg_r * n_bwd}
         for key, name, names in (
-                ("forward", "rsn_field_kernel<%d,true,%d>" % (args.width // 32, {"bf16x6": 1, "bf16": 3}.get(args.mma, 0)),
+                ("forward", "rsn_field_bf16_train_kernel<normals>" if ring else "rsn_field_kernel<%d,true,%d>" % (args.width // 32, mi),
                  ("field_forward_train_normals", "field_forward_train")),
-                ("backward", "rsn_field_bwd_kernel<%d,%d>" % (args.width // 32, {"bf16x6": 1, "bf16": 3}.get(args.mma, 0)),
+                ("backward", "rsn_field_bf16_bwd_kernel<input>" if ring else "rsn_field_bwd_kernel<%d,%d>" % (args.width // 32, mi),
                  ("field_backward", "field_backward_input")),
                 ("wgrad", "rsn_wgrad_kernel", ("weight_grad",))):
             t_ms = sum(ms(n) for n in names)
@@ -336,6 +355,11 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
             kern[key] = {"kernel": name, "launches_per_step": n_calls / steps, "avg_launch_ms": t_ms / max(n_calls, 1),
                          "ms_per_step": t_ms / steps, "algorithmic_flop_per_step": flop[key] / steps,
                          "achieved_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS}
+            if args.mma == "bf16":  # this mode's two rooflines: the dense bf16 MFMA peak and the HBM stream of the saved rows
+                tbps = hbm[key] / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+                kern[key].update({"frac_of_bf16_mfma_peak": tf / BF16_MFMA_PEAK_TFLOPS,
+                                  "algorithmic_hbm_bytes_per_step": hbm[key] / steps, "achieved_hbm_tbps": tbps,
+                                  "frac_of_hbm_peak": tbps / HBM_PEAK_TBPS})
         total_flop = sum(flop.values()) / steps
         # the same, split by launch kind (primary levels carry the analytic-normal sweep / no input gradient)
         per_kind = {}
@@ -674,14 +698,21 @@ def main():
                                min(max(args.warmup, 1), 3), dog, time_kernels=False)
                 bf_args = argparse.Namespace(**{**vars(args), "mma": "bf16"})
                 bf = run_train(pkg, bf_args, dev, rank, world, None, share, samples, min(args.steps, 10),
-                               min(max(args.warmup, 1), 3), dog, time_kernels=False)
+                               min(max(args.warmup, 1), 3), dog, time_kernels=True)
                 line["eval_level"] = lv
                 line["eval_image"] = run_eval_image(pkg, args, dev, dog)
                 line["train_step_bf16_sweeps"] = {
                     "workload": "the headline step in REDUCED precision (opt-in; the reference itself trains under fp16 "
-                                "autocast, config.py:33): forward / backward sweeps with plain bf16 MFMA operands and fp32 "
-                                "accumulation, weight-gradient operands rounded to bf16 in-kernel (fp32-saved activations, fp32 accumulation)",
-                    **{k: bf[k] for k in ("value", "unit", "ms_per_step", "steps")}}
+                                "autocast, config.py:33): forward (with the analytic-normal sweep) and backward sweeps on plain bf16 "
+                                "MFMA operands with fp32 accumulation, weights shared per workgroup through an LDS ring "
+                                "(rsn_field_bf16_train.hip); saved activations / layer gradients are bf16 rows, read as such by the "
+                                "weight-gradient kernel (fp32 accumulation)",
+                    **{k: bf[k] for k in ("value", "unit", "ms_per_step", "steps", "peak_device_memory_gb")},
+                    "roofline": {"note": "two rooflines per kernel: algorithmic FLOP / time against the 2.5 PF dense bf16 MFMA peak, and "
+                                         "algorithmic HBM bytes of the saved rows / time against 8 TB/s (HIP events on the launch stream)",
+                                 **{k: {q: v[q] for q in ("kernel", "ms_per_step", "achieved_tflops", "frac_of_bf16_mfma_peak",
+                                                          "algorithmic_hbm_bytes_per_step", "achieved_hbm_tbps", "frac_of_hbm_peak")}
+                                    for k, v in bf["kernels"].items()}}}
                 line["train_step_bf16x6_sweeps"] = {
                     "workload": "the headline step with the forward / backward sweeps on split-bf16 MFMA (3-way split, 6 "
                                 "products, fp32 accumulate: fp32-equivalent, opt-in); weight-gradient operands split the same way in-kernel",

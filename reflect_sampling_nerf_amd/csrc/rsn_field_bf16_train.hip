@@ -26,28 +26,48 @@
 #include "rsn_field_bwd_common.h"
 #include "rsn_ring16.h"
 
-#define RT_LEAD 3                      // ring groups in flight ahead of the one being consumed
-#define RT_SLOTS (RT_LEAD + 1)
+// ring groups in flight ahead of the one being consumed.  The consumer's counted wait lets the row stores of the last LEAD - 1
+// group intervals stay in flight (vmcnt retires in order behind the weight group's LDS-DMA), so LEAD bounds the bytes each wave
+// keeps on their way to HBM: 2 KiB per interval.  Measured (profiles/r04_bf16_train_ab.txt): depth is NOT what limits the store
+// stream -- forward 3 / 4 groups ahead 1.22 / 1.28 ms, backward 3 / 5 / 7 groups 0.80 / 0.78 / 0.78 ms per primary level.
+#ifndef RT_LEAD_FWD
+#define RT_LEAD_FWD 3
+#endif
+#ifndef RT_LEAD_BWD
+#define RT_LEAD_BWD 5
+#endif
+// Cache policy of the saved-row stores (buffer-instruction aux bits: 1 sc0, 2 nt, 16 sc1): NON-TEMPORAL.  The rows (3 GB per
+// primary-level launch) are not read again by the kernel that writes them; with the default policy they push the 2.4 MB
+// weight stream out of the XCD's 4 MiB L2 and every workgroup's LDS-DMA then comes from beyond it: forward with normals
+// 1.83 -> 1.22 ms per launch, backward 1.05 -> 0.78 ms, the step 11.0 -> 8.7 ms (sc1: no change; nt + sc1 as nt).  (The
+// exact-fp32 kernels measured the opposite in round 3 -- there the stores share the vector-memory path with a per-wave
+// weight stream that is L2-bound either way.)
+#ifndef RT_STORE_AUX
+#define RT_STORE_AUX 2
+#endif
 #define RT_PPW (RSN_RING_GROUP_FRAGS / 8)
-#define RT_RING_BYTES (RT_SLOTS * RING_GROUP_BYTES)
 #define RT_TABLE_FLOATS (RING_BIAS_FLOATS + 256)   // biases (packed row order) + the density-head row (normal-sweep seed)
-#define RT_LDS_BYTES (RT_RING_BYTES + 8 * R16_STASH_BYTES + RT_TABLE_FLOATS * 4)
+#define RT_RING_BYTES(LEAD) (((LEAD) + 1) * RING_GROUP_BYTES)
 
 typedef unsigned u32x2t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ the ring, with a program
+template <int LEAD>
 struct RingT {
+  static constexpr int SLOTS = LEAD + 1;
   const char* src;     // q_stream base + wave * PPW KiB
   unsigned lane16, lds_dst;
   int issue_grp, issue_slot;
   int e0, j0, e1, j1;  // the walk: group e_i - 1 is followed by group j_i (two jumps describe every program below)
   unsigned rd_base, rd_cur, rd_next;
   int next_slot;
-  int c0, c1;          // counted vector-memory operations (row stores) issued since the last / in the previous group boundary
+  int c0;              // counted vector-memory operations (row stores) issued since the last group boundary ...
+  int cp[LEAD - 2];    // ... and in the LEAD - 2 intervals before it (cp[0] the newest)
 };
 
-__device__ __forceinline__ void ringt_issue(RingT& r) {
+template <int LEAD>
+__device__ __forceinline__ void ringt_issue(RingT<LEAD>& r) {
   const char* g = r.src + (size_t)r.issue_grp * RING_GROUP_BYTES;
   const unsigned d = __builtin_amdgcn_readfirstlane(r.lds_dst + (unsigned)r.issue_slot * RING_GROUP_BYTES);
 #pragma unroll
@@ -55,7 +75,7 @@ __device__ __forceinline__ void ringt_issue(RingT& r) {
   int n = r.issue_grp + 1;
   n = (n == r.e0) ? r.j0 : ((n == r.e1) ? r.j1 : n);
   r.issue_grp = n;
-  r.issue_slot = (r.issue_slot + 1 == RT_SLOTS) ? 0 : r.issue_slot + 1;
+  r.issue_slot = (r.issue_slot + 1 == RingT<LEAD>::SLOTS) ? 0 : r.issue_slot + 1;
 }
 
 // s_waitcnt vmcnt(n) with a wave-uniform n that the fully unrolled GEMMs fold to a constant almost everywhere (the field is an
@@ -63,31 +83,37 @@ __device__ __forceinline__ void ringt_issue(RingT& r) {
 // jump table inside the GEMM loop keeps hipcc from unrolling it (and the accumulators then live in scratch).
 #define RT_WAIT_STEP(k) if (n >= k) { asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); return; }
 __device__ __forceinline__ void wait_vm(int n) {
-  RT_WAIT_STEP(16) RT_WAIT_STEP(14) RT_WAIT_STEP(12) RT_WAIT_STEP(10) RT_WAIT_STEP(9) RT_WAIT_STEP(8) RT_WAIT_STEP(7)
-  RT_WAIT_STEP(6) RT_WAIT_STEP(5) RT_WAIT_STEP(4) RT_WAIT_STEP(3) RT_WAIT_STEP(2) RT_WAIT_STEP(1)
+  RT_WAIT_STEP(40) RT_WAIT_STEP(36) RT_WAIT_STEP(32) RT_WAIT_STEP(28) RT_WAIT_STEP(26) RT_WAIT_STEP(24) RT_WAIT_STEP(22)
+  RT_WAIT_STEP(20) RT_WAIT_STEP(18) RT_WAIT_STEP(16) RT_WAIT_STEP(14) RT_WAIT_STEP(12) RT_WAIT_STEP(10) RT_WAIT_STEP(9)
+  RT_WAIT_STEP(8) RT_WAIT_STEP(7) RT_WAIT_STEP(6) RT_WAIT_STEP(5) RT_WAIT_STEP(4) RT_WAIT_STEP(3) RT_WAIT_STEP(2) RT_WAIT_STEP(1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 #undef RT_WAIT_STEP
 
-// Group boundary.  The LDS-DMA of the group after the one about to be consumed was issued RT_LEAD - 1 boundaries ago; behind it
-// in the in-order vmcnt queue sit the counted stores of the last RT_LEAD - 1 intervals and the DMA of RT_LEAD - 2 boundaries:
+// Group boundary.  The LDS-DMA of the group after the one about to be consumed was issued LEAD - 1 boundaries ago; behind it
+// in the in-order vmcnt queue sit the counted stores of the last LEAD - 1 intervals and the DMA of LEAD - 2 boundaries:
 // "at most that many outstanding" = that DMA (and everything older) has landed.  Uncounted operations (per-sample loads /
 // stores the compiler issues on its own) only make the wait stricter.
-__device__ __forceinline__ void ringt_sync(RingT& r) {
-  static_assert(RT_LEAD == 3, "the counters cover two intervals");
-  wait_vm(r.c0 + r.c1 + RT_PPW * (RT_LEAD - 2));
+template <int LEAD>
+__device__ __forceinline__ void ringt_sync(RingT<LEAD>& r) {
+  int n = r.c0 + RT_PPW * (LEAD - 2);
+#pragma unroll
+  for (int i = 0; i < LEAD - 2; ++i) n += r.cp[i];
+  wait_vm(n);
   asm volatile("s_barrier" ::: "memory");
   ringt_issue(r);
-  r.c1 = r.c0;
+#pragma unroll
+  for (int i = LEAD - 3; i > 0; --i) r.cp[i] = r.cp[i - 1];
+  r.cp[0] = r.c0;
   r.c0 = 0;
   r.rd_cur = r.rd_next;
-  r.next_slot = (r.next_slot + 1 == RT_SLOTS) ? 0 : r.next_slot + 1;
+  r.next_slot = (r.next_slot + 1 == RingT<LEAD>::SLOTS) ? 0 : r.next_slot + 1;
   r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
 }
 
 // acc[b][p] += W-fragment(i) * X[kk][p]; `hook(group)` runs right behind every group boundary (the kernels put their row stores there)
-template <int NBO, int KS, int XN, class HOOK>
-__device__ __forceinline__ void gemm_t(f32x4 (&acc)[NBO][2], const bf16x8 (&X)[XN][2], RingT& r, bf16x8 (&W)[RING_FIFO],
+template <int NBO, int KS, int XN, int LEAD, class HOOK>
+__device__ __forceinline__ void gemm_t(f32x4 (&acc)[NBO][2], const bf16x8 (&X)[XN][2], RingT<LEAD>& r, bf16x8 (&W)[RING_FIFO],
                                        const char* smem, HOOK&& hook) {
   static_assert((NBO * KS) % RSN_RING_GROUP_FRAGS == 0 && KS <= XN, "a GEMM is a whole number of ring groups");
   // (two nested loops, not one with `if (i % 16 == 0)`: hipcc prices the unrolled size BEFORE it folds the wait's if-chain, and
@@ -133,20 +159,39 @@ __device__ __forceinline__ RowD rowd(const void* base, long long byte_off, int r
                                           base != nullptr ? rows * row_bytes : 0, 0x00020000);
   return d;
 }
-__device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff, const bf16x8 v, RingT& r) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, v), d.r, voff, soff, 0);
+// (RSN_RT_*: timing ablations of tools/bf16_train_ab.sh -- wrong results by construction; they compile only under -DRSN_DIAG_BUILD)
+template <int LEAD>
+__device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff, const bf16x8 v, RingT<LEAD>& r) {
+#ifndef RSN_RT_NO_STORES
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, v), d.r, voff, soff, RT_STORE_AUX);
+#ifndef RSN_RT_UNCOUNTED
   r.c0 += 1;
+#endif
+#endif
 }
-__device__ __forceinline__ void st8(const RowD& d, unsigned voff, unsigned soff, unsigned w0, unsigned w1, RingT& r) {
+template <int LEAD>
+__device__ __forceinline__ void st8(const RowD& d, unsigned voff, unsigned soff, unsigned w0, unsigned w1, RingT<LEAD>& r) {
+#ifndef RSN_RT_NO_STORES
   const u32x2t v = {w0, w1};
   __builtin_amdgcn_raw_buffer_store_b64(v, d.r, voff, soff, 0);
+#ifndef RSN_RT_UNCOUNTED
   r.c0 += 1;
+#endif
+#endif
 }
 __device__ __forceinline__ bf16x8 ld16(const RowD& d, unsigned voff, unsigned soff) {  // glc: written earlier by this kernel
+#ifdef RSN_RT_NO_LOADS
+  return bf16x8{};
+#else
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(d.r, voff, soff, 1));
+#endif
 }
 __device__ __forceinline__ u32x2t ld8(const RowD& d, unsigned voff, unsigned soff) {
+#ifdef RSN_RT_NO_LOADS
+  return u32x2t{0xffffffffu, 0xffffffffu};
+#else
   return __builtin_amdgcn_raw_buffer_load_b64(d.r, voff, soff, 1);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ ReLU bits on packed bf16
@@ -164,6 +209,9 @@ __device__ __forceinline__ unsigned pk_mul_lo_u16(unsigned a, unsigned b) {
 // (low half > 0) at bit 15 - j and (high half > 0) at bit 31 - j
 template <int XN>
 __device__ __forceinline__ unsigned relu_bits_of(const bf16x8 (&X)[XN][2], int p, int kk0, unsigned one2) {
+#ifdef RSN_RT_NO_BITS
+  return 0xffffffffu;
+#endif
   unsigned b = 0u;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -175,7 +223,11 @@ __device__ __forceinline__ unsigned relu_bits_of(const bf16x8 (&X)[XN][2], int p
 }
 // packed gradient word (K-step kk, word wi) masked by those bits
 __device__ __forceinline__ unsigned mask_word(unsigned gword, unsigned bits, int j, unsigned one2) {
+#ifdef RSN_RT_NO_BITS
+  return gword;
+#else
   return pk_mul_lo_u16(gword, (bits >> (15 - j)) & one2);
+#endif
 }
 
 // accumulators -> packed bf16 B operand of the next GEMM (no activation), masked by the layer's ReLU bits (2 words per point)
@@ -250,7 +302,8 @@ __device__ __forceinline__ TileJobs tile_space(const JOBS& J) {
   return t;
 }
 
-__device__ __forceinline__ void ring_start(RingT& r, const float* pk, const RsnPackedLayout& L, const char* smem, int wid, int lane,
+template <int LEAD>
+__device__ __forceinline__ void ring_start(RingT<LEAD>& r, const float* pk, const RsnPackedLayout& L, const char* smem, int wid, int lane,
                                            int first, int e0, int j0, int e1, int j1, bf16x8 (&Wf)[RING_FIFO]) {
   r.src = reinterpret_cast<const char*>(pk + L.q_stream) + wid * (RT_PPW * 1024);
   r.lane16 = (unsigned)lane * 16u;
@@ -262,11 +315,13 @@ __device__ __forceinline__ void ring_start(RingT& r, const float* pk, const RsnP
   r.next_slot = 0;
   r.rd_next = r.rd_base;
   r.rd_cur = r.rd_base;
-  r.c0 = 0; r.c1 = 0;
+  r.c0 = 0;
+#pragma unroll
+  for (int i = 0; i < LEAD - 2; ++i) r.cp[i] = 0;
   __syncthreads();  // nothing in flight yet (also publishes the LDS tables)
 #pragma unroll
-  for (int gq = 0; gq < RT_LEAD; ++gq) ringt_issue(r);
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RT_PPW * (RT_LEAD - 1)) : "memory");
+  for (int gq = 0; gq < LEAD; ++gq) ringt_issue(r);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RT_PPW * (LEAD - 1)) : "memory");
 #pragma unroll
   for (int j = 0; j < RING_FIFO; ++j) Wf[j] = *reinterpret_cast<const bf16x8*>(smem + r.rd_next + j * 1024);
 }
@@ -275,12 +330,13 @@ __device__ __forceinline__ void ring_start(RingT& r, const float* pk, const RsnP
 template <bool NORMALS>
 __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const FieldJobs J) {
   constexpr int W = 256;
-  __shared__ __attribute__((aligned(1024))) char smem[RT_LDS_BYTES];
+  constexpr int RB = RT_RING_BYTES(RT_LEAD_FWD);
+  __shared__ __attribute__((aligned(1024))) char smem[RB + 8 * R16_STASH_BYTES + RT_TABLE_FLOATS * 4];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* stash = smem + RT_RING_BYTES + wid * R16_STASH_BYTES;
+  char* stash = smem + RB + wid * R16_STASH_BYTES;
   bf16x8* ST = reinterpret_cast<bf16x8*>(stash) + lane;   // fragment (kk, p) of this lane: ST[(kk * 2 + p) * 64]
-  float* bias = reinterpret_cast<float*>(smem + RT_RING_BYTES + 8 * R16_STASH_BYTES);
+  float* bias = reinterpret_cast<float*>(smem + RB + 8 * R16_STASH_BYTES);
   const float* b_bh = bias + RING_MAX_LAYERS * 256;
   const float* b_mid = b_bh + 288;
   const float* b_rgb = b_mid + 128;
@@ -298,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
   if (threadIdx.x < 32) bias[RING_MAX_LAYERS * 256 + 288 + 128 + threadIdx.x] = pk[P.L.b_rgb + threadIdx.x];
   if (threadIdx.x < 256) bias[RING_BIAS_FLOATS + threadIdx.x] = pk[P.L.v_density + threadIdx.x];
 
-  RingT r;
+  RingT<RT_LEAD_FWD> r;
   bf16x8 Wf[RING_FIFO];
   // the walk: forward stream [0, q_groups); with the normal sweep then [t_g_trunk, t_g_end) of the transposed stream; again
   ring_start(r, pk, P.L, smem, wid, lane, 0, P.L.q_groups, NORMALS ? P.L.t_g_trunk : 0, NORMALS ? P.L.t_g_end : -1, 0, Wf);
@@ -589,7 +645,11 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
     }
 
     // ---------------- analytic normals: -normalize(d raw_density / d contracted mean) -----------------
+#ifdef RSN_RT_NO_SWEEP
+    if (false) {
+#else
     if (NORMALS) {
+#endif
       // seed: the density-head row masked by the embedding's ReLU
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
@@ -657,7 +717,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
 template <bool INPUT>
 __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJobs J) {
   constexpr int W = 256;
-  __shared__ __attribute__((aligned(1024))) char smem[RT_RING_BYTES];
+  __shared__ __attribute__((aligned(1024))) char smem[RT_RING_BYTES(RT_LEAD_BWD)];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const BwdShared& P = J.s;
@@ -666,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
   const float* __restrict__ pk = P.packed;
   const int L = P.num_layers;
 
-  RingT r;
+  RingT<RT_LEAD_BWD> r;
   bf16x8 Wf[RING_FIFO];
   // the walk: the whole transposed stream; without an input gradient the two encoded-input pieces are jumped over
   {

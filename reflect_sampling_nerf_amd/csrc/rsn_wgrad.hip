@@ -21,6 +21,11 @@
 // MFMA-bound: 2 * N * n_out * k_in FLOP; HBM reads N * (n_out + k_in) * 4 B (each operand once per workgroup).
 #include "rsn_mfma.h"
 
+// cache policy of the operand-row loads (buffer-instruction aux bits: 2 = nt); A/B switch of tools/bf16_train_ab.sh
+#ifndef WG_LOAD_AUX
+#define WG_LOAD_AUX 0
+#endif
+
 #define WG_MAX_SEG 8
 
 struct WGradArgs {
@@ -210,41 +215,41 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
         const_cast<char*>(reinterpret_cast<const char*>(xp)) + m0 * a.ld_x * XBPE, 0, 0x7fffffff, 0x00020000);
     const unsigned sd = (unsigned)(prow(p) * a.ld_dy * DBPE), sx = (unsigned)(prow(p) * a.ld_x * XBPE);
     if constexpr (DB) {
-      ua[buf][p] = __builtin_amdgcn_raw_buffer_load_b32(rd, vd[0], sd, 0);
+      ua[buf][p] = __builtin_amdgcn_raw_buffer_load_b32(rd, vd[0], sd, WG_LOAD_AUX);
     } else if constexpr (DV) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rd, vd[0], sd, 0);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rd, vd[0], sd, WG_LOAD_AUX);
       fa[buf][p][0] = __uint_as_float(v.x);
       fa[buf][p][1] = __uint_as_float(v.y);
     } else {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fa[buf][p][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vd[t], sd, 0));
+      for (int t = 0; t < 2; ++t) fa[buf][p][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, vd[t], sd, WG_LOAD_AUX));
     }
     if constexpr (XB) {
       if constexpr (NKB == 8) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, vx[0], sx, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, vx[0], sx, WG_LOAD_AUX);
         ub[buf][p][0] = v.x; ub[buf][p][1] = v.y; ub[buf][p][2] = v.z; ub[buf][p][3] = v.w;
       } else if constexpr (NKB == 4) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, vx[0], sx, 0);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, vx[0], sx, WG_LOAD_AUX);
         ub[buf][p][0] = v.x; ub[buf][p][1] = v.y;
       } else {
-        ub[buf][p][0] = __builtin_amdgcn_raw_buffer_load_b32(rx, vx[0], sx, 0);
+        ub[buf][p][0] = __builtin_amdgcn_raw_buffer_load_b32(rx, vx[0], sx, WG_LOAD_AUX);
       }
     } else if constexpr (XV && NKB >= 4) {
 #pragma unroll
       for (int q = 0; q < NKB / 4; ++q) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, vx[0], sx + 16u * q, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, vx[0], sx + 16u * q, WG_LOAD_AUX);
         fb[buf][p][4 * q + 0] = __uint_as_float(v.x);
         fb[buf][p][4 * q + 1] = __uint_as_float(v.y);
         fb[buf][p][4 * q + 2] = __uint_as_float(v.z);
         fb[buf][p][4 * q + 3] = __uint_as_float(v.w);
       }
     } else if constexpr (XV) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, vx[0], sx, 0);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, vx[0], sx, WG_LOAD_AUX);
       fb[buf][p][0] = __uint_as_float(v.x);
       fb[buf][p][1] = __uint_as_float(v.y);
     } else {
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) fb[buf][p][kb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[kb], sx, 0));
+      for (int kb = 0; kb < NKB; ++kb) fb[buf][p][kb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[kb], sx, WG_LOAD_AUX));
     }
   };
   // the split-bf16 variant (BF = 3) keeps the pointer loads: with buffer loads its loop ran 5 % slower (10.8 against 10.25 ms
