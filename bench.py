@@ -499,6 +499,8 @@ def run_eval_image(pkg, args, dev, dog, side=800, chunks=(1024, 4096, 16384), re
             model.field.field_output_density.net.bias += 2.0
         model.to(dev).eval()
         model.field.set_mma_mode(args.mma)
+        if os.environ.get("RSN_EVAL_SIDE_STREAMS"):  # A/B of the chunk overlap (default: three side streams)
+            model.eval_side_streams = int(os.environ["RSN_EVAL_SIDE_STREAMS"])
         best = None
         for rep in range(repeats + 1):  # the first pass warms the allocator up and is not counted
             torch.cuda.synchronize()

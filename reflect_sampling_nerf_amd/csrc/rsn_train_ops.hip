@@ -181,8 +181,24 @@ struct LossRaysArgs {
   float* g_rgb[4];
 };
 
-__global__ __launch_bounds__(256) void rsn_loss_rays_kernel(const LossRaysArgs a) {
-  __shared__ float sh[4];
+// ONE workgroup of 1024 threads: the eight reported loss values are reduced in a FIXED order (per-thread strided sums, a wave
+// butterfly, the sixteen wave sums in index order) and are bit-reproducible from run to run -- the data is a few hundred KB,
+// a second workgroup would only add float atomics whose arrival order varies (the gradients never depended on it).
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  float t = 0.0f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += sh[w];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void rsn_loss_rays_kernel(const LossRaysArgs a) {
+  __shared__ float sh[16];
   float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int stride = gridDim.x * blockDim.x;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,9 +222,9 @@ __global__ __launch_bounds__(256) void rsn_loss_rays_kernel(const LossRaysArgs a
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float v = block_sum_256(part[k], sh);
+    float v = block_sum_1024(part[k], sh);
     if (k < 4) v *= inv;
-    if (threadIdx.x == 0) atomicAdd(&a.losses[k], v);
+    if (threadIdx.x == 0) a.losses[k] = v;
   }
 }
 
@@ -227,10 +243,7 @@ extern "C" int rsn_loss_rays_forward(int32_t n_rays, const float* image, const f
   }
   for (int k = 0; k < 8; ++k) a.coef[k] = coef8[k];
   hipStream_t st = (hipStream_t)stream;
-  RSN_HIP(hipMemsetAsync(losses8, 0, 8 * sizeof(float), st));
-  int blocks = (n_rays * 3 + 255) / 256;
-  if (blocks > 64) blocks = 64;  // 8 atomics per block: few blocks, the data is a few hundred KB
-  hipLaunchKernelGGL(rsn_loss_rays_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(rsn_loss_rays_kernel, dim3(1), dim3(1024), 0, st, a);  // one workgroup: fixed-order sums (see the kernel)
   RSN_HIP(hipGetLastError());
   return RSN_OK;
 }

@@ -13,8 +13,11 @@ the caller enqueues that does not touch the gradients overlaps with the collecti
 
   * Which parameters never receive a gradient on any rank (field_output_low: built by field.py:67, never evaluated)
     is decided on the first call by one extra flag all-reduce; they are dropped from the flat buffer.  Should a dropped
-    parameter receive a gradient later (a host-side check of `.grad is not None`, no device read), the decision is taken
-    again, so replicas cannot diverge silently.
+    parameter receive a gradient on SOME rank later, that rank raises a "revive" flag in the tail of the flat buffer --
+    the buffer every rank reduces every step anyway -- and drops the gradient for this one step; the reduced flag is
+    copied to pinned host memory asynchronously and looked at one step late (its event has long fired: no stall), where
+    EVERY rank sees the same value and takes the decision again in the same call, the new live set united with the old
+    one.  No rank-local condition ever selects which collective is issued (a mismatch would hang RCCL).
   * The per-step "was used" flags of the live parameters travel in the tail of the same flat buffer.  They are kept on
     the device (one cached tensor per distinct None-pattern) and are only read back on a step where THIS rank lacks a
     gradient some other rank may have produced -- which the reflect-sampling model never does (train_graph.py hands
@@ -44,9 +47,13 @@ class FlatGradAllReduce:
 
     # ------------------------------------------------------------------------------------------------ one-time set-up
     def _decide_live(self) -> None:
-        """First call only: parameters without a gradient on EVERY rank are statically unused -> never reduced."""
+        """Parameters without a gradient on EVERY rank are statically unused -> never reduced.  Taken on the first call and
+        again -- by all ranks in the same call -- one step after any rank has flagged a gradient on a dropped parameter;
+        a parameter once live stays live (a step without its gradient contributes zeros)."""
         p0 = self.all_params[0]
-        have = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.all_params], dtype=torch.float32)
+        was_live = set() if self.params is None else {id(p) for p in self.params}
+        have = torch.tensor([1.0 if (p.grad is not None or id(p) in was_live) else 0.0 for p in self.all_params],
+                            dtype=torch.float32)
         gloo = dist.get_backend(self.group) == "gloo"
         t = have if gloo else have.to(p0.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -56,10 +63,14 @@ class FlatGradAllReduce:
         self._dropped = [p for p, u in zip(self.all_params, used.tolist()) if u <= 0.0]
         self.sizes = [p.numel() for p in self.params]
         self.total = sum(self.sizes)
-        n = self.total + len(self.params)  # gradients + one "was used" flag per live parameter
+        n = self.total + len(self.params) + 1  # gradients + one "was used" flag per live parameter + the revive flag
         self._flat = torch.zeros(n, device=p0.device, dtype=p0.dtype)
         self._views = [v.view_as(p) for v, p in zip(self._flat[: self.total].split(self.sizes), self.params)]
-        if self.use_side_stream and p0.is_cuda:
+        self._flags = {}
+        self._revive_host = torch.zeros(1, dtype=p0.dtype, pin_memory=p0.is_cuda)  # last step's reduced revive flag
+        self._revive_ev = torch.cuda.Event() if p0.is_cuda else None
+        self._revive_pending = False
+        if self.use_side_stream and p0.is_cuda and self._stream is None:
             self._stream = torch.cuda.Stream(device=p0.device)
             self._packed_ev = torch.cuda.Event()
             self._reduced_ev = torch.cuda.Event()
@@ -81,11 +92,20 @@ class FlatGradAllReduce:
             return
         if self.params is None:
             self._decide_live()
-        elif any(p.grad is not None for p in self._dropped):
-            # a parameter that had no gradient on ANY rank at the first step has one now (host-only check, no device read):
-            # decide again -- every rank must then do so in the same step, which holds when the model's control flow is the
-            # same on all ranks (DDP with find_unused_parameters=True re-discovers unused parameters every step)
-            self._decide_live()
+        elif self._revive_pending:
+            # last step's REDUCED revive flag (the same number on every rank): copied to pinned memory behind that step's
+            # all-reduce, its event fired long ago.  Non-zero: some rank saw a gradient on a dropped parameter -> every rank
+            # takes the decision again, here, together.
+            if self._revive_ev is not None:
+                self._revive_ev.synchronize()
+            self._revive_pending = False
+            if float(self._revive_host[0]) > 0.0:
+                self._decide_live()
+        revive = False
+        for p in self._dropped:
+            if p.grad is not None:  # host-only check.  Only this rank may have it: not applied this step (replicas stay
+                p.grad = None       # identical); flagged, and reduced from the next step on
+                revive = True
         flat = self._flat
         have = tuple(p.grad is not None for p in self.params)
         complete = all(have)
@@ -96,7 +116,7 @@ class FlatGradAllReduce:
         dst = self._views if complete else [v for v, h in zip(self._views, have) if h]
         if src:
             torch._foreach_copy_(dst, src)
-        flat[self.total:].copy_(self._flag_tensor(have))
+        flat[self.total:].copy_(self._flag_tensor(have + (revive,)))
         gloo_cuda = dist.get_backend(self.group) == "gloo" and flat.is_cuda
         if gloo_cuda:  # CPU rehearsal backend (two ranks sharing one GPU): stage through the host
             host = flat.cpu()
@@ -115,13 +135,20 @@ class FlatGradAllReduce:
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat[: self.total].mul_(1.0 / world)
+        # the reduced revive flag goes to pinned host memory asynchronously; the NEXT call looks at it
+        if flat.is_cuda:
+            self._revive_host.copy_(flat[-1:], non_blocking=True)
+            self._revive_ev.record(torch.cuda.current_stream(flat.device))
+        else:
+            self._revive_host.copy_(flat[-1:])
+        self._revive_pending = True
         # unpack: gradients that exist locally are overwritten in one multi-tensor copy
         if src:
             torch._foreach_copy_(src, dst)
         if not complete:
             # this rank lacks a gradient: the summed flags tell "zeros from me, data from others" apart from "unused
             # on every rank this step -> stays None" (DDP, find_unused_parameters=True).  The only host read.
-            used = flat[self.total:].cpu()
+            used = flat[self.total:-1].cpu()
             self.host_syncs += 1
             for i, (p, h) in enumerate(zip(self.params, have)):
                 if not h and float(used[i]) > 0.0:

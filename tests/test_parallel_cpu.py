@@ -55,15 +55,35 @@ def _worker(rank, world, port, out):
             ok &= torch.allclose(params[i].grad, torch.full_like(params[i], 1.5 + step))
         ok &= params[3].grad is None
     ok &= reducer.host_syncs == syncs_before
-    # a parameter dropped as "never used" receives a gradient later (on every rank): the reducer notices on the host,
-    # decides again (one more flag all-reduce) and averages it from then on -- replicas cannot diverge silently
-    params[3].grad = torch.full_like(params[3], float(rank + 1))
+    # a parameter dropped as "never used" receives a gradient later ON ONE RANK ONLY (rank 1).  No rank-local condition may
+    # select the collective (the other rank would sit in a different all-reduce: a hang under RCCL): rank 1 raises the revive
+    # flag inside the flat buffer both ranks reduce anyway and drops that gradient for this one step (replicas stay identical) ...
     for i in range(3):
         params[i].grad = torch.full_like(params[i], float(rank))
+    if rank == 1:
+        params[3].grad = torch.full_like(params[3], 8.0)
     reducer()
-    ok &= len(reducer.params) == 4 and torch.allclose(params[3].grad, torch.full_like(params[3], 1.5))
+    ok &= len(reducer.params) == 3 and params[3].grad is None
     ok &= torch.allclose(params[0].grad, torch.full_like(params[0], 0.5))
-    ok &= reducer.host_syncs == syncs_before + 1
+    ok &= reducer.host_syncs == syncs_before
+    # ... and one step later BOTH ranks see the reduced flag, take the decision again together (one more flag all-reduce: the one
+    # extra host read) and average the revived parameter from then on -- also on a rank that has no gradient for it
+    for i in range(3):
+        params[i].grad = torch.full_like(params[i], float(rank))
+    if rank == 1:
+        params[3].grad = torch.full_like(params[3], 8.0)
+    reducer()
+    ok &= len(reducer.params) == 4 and params[3].grad is not None and torch.allclose(params[3].grad, torch.full_like(params[3], 4.0))
+    ok &= torch.allclose(params[0].grad, torch.full_like(params[0], 0.5))
+    ok &= reducer.host_syncs <= syncs_before + 2  # the decision (+ rank 0's read of the used-flags: it lacks a gradient rank 1 has)
+    # a live parameter without a gradient on every rank this step keeps None; it stays live (no re-decision ping-pong)
+    for i in range(3):
+        params[i].grad = torch.full_like(params[i], 1.0)
+    params[3].grad = None
+    n_sync = reducer.host_syncs
+    reducer()
+    ok &= len(reducer.params) == 4 and params[3].grad is None
+    ok &= reducer.host_syncs == n_sync + 1  # the used-flags read of a rank that lacks a live gradient, not a new decision
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
