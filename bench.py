@@ -117,6 +117,9 @@ def parse():
     ap.add_argument("--ray-chunk", type=int, default=0,
                     help="train: walk the batch in chunks of this many rays (gradient accumulation, exact; bounds the "
                          "activation memory). 0 = the whole batch at once")
+    ap.add_argument("--reflect-capacity", default="", choices=["", "auto"],
+                    help="train: size the reflect levels' buffers from the previous step's reflected-ray count (opt-in: "
+                         "train_graph.reflect_capacity) instead of for all rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (eval_level, configs[2])")
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays of the bounded CPU-baseline sample (0 = auto)")
@@ -274,6 +277,8 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
     with torch.no_grad():
         model.field.field_output_density.net.bias += 2.0  # so that the reflect branch is exercised
     model.to(dev).train()
+    if getattr(args, "reflect_capacity", ""):
+        model.reflect_capacity = args.reflect_capacity
     model.field.set_mma_mode(args.mma if args.mma in ("f32", "bf16x6", "bf16") else "f32")
     o, d, pa = synthetic_rays(R, seed=rank)  # each rank renders its own rays
     rb = pkg.RayBundle(origins=o.to(dev), directions=d.to(dev), pixel_area=pa.reshape(R, 1).to(dev),
@@ -311,7 +316,9 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
            "warmup": warmup, "n_gpus": world, "loss": float(state["loss"]),
            "reflect_ray_fraction": state["M"] / float(steps * R), "host_syncs_in_reducer":
                (reducer.host_syncs if reducer is not None else 0),
-           "peak_device_memory_gb": torch.cuda.max_memory_allocated() / 2**30, "ray_chunk": args.ray_chunk or None}
+           "peak_device_memory_gb": torch.cuda.max_memory_allocated() / 2**30, "ray_chunk": args.ray_chunk or None,
+           "reflect_capacity": getattr(args, "reflect_capacity", "") or None,
+           "reflect_overflows": getattr(model, "reflect_overflows", 0)}
     if timer is not None:
         tot = timer.totals()
         pts = lambda k: tot.get(k, {"work": {}})["work"].get("points", 0)  # noqa: E731

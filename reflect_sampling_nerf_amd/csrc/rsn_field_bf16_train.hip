@@ -45,17 +45,27 @@
 #ifndef RT_STORE_AUX
 #define RT_STORE_AUX 2
 #endif
+// Stagger: waves 4..7 (the second wave of every SIMD) run STAG ring groups BEHIND waves 0..3 in the same instruction stream, so
+// that the two waves of a SIMD are never in a layer epilogue (VALU only: pack, ReLU bits / masks, row addressing) at the same
+// time -- one wave's epilogue runs under the other's MFMAs.  The ring holds the groups in between: LEAD + STAG + 1 slots.
+#ifndef RT_STAG_FWD
+#define RT_STAG_FWD 0
+#endif
+#ifndef RT_STAG_BWD
+#define RT_STAG_BWD 0
+#endif
 #define RT_PPW (RSN_RING_GROUP_FRAGS / 8)
 #define RT_TABLE_FLOATS (RING_BIAS_FLOATS + 256)   // biases (packed row order) + the density-head row (normal-sweep seed)
-#define RT_RING_BYTES(LEAD) (((LEAD) + 1) * RING_GROUP_BYTES)
+#define RT_RING_BYTES(LEAD, STAG) (((LEAD) + (STAG) + 1) * RING_GROUP_BYTES)
 
 typedef unsigned u32x2t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ the ring, with a program
-template <int LEAD>
+template <int LEAD, int STAG = 0>
 struct RingT {
-  static constexpr int SLOTS = LEAD + 1;
+  static constexpr int SLOTS = LEAD + STAG + 1;
+  static constexpr int kLead = LEAD, kStag = STAG;
   const char* src;     // q_stream base + wave * PPW KiB
   unsigned lane16, lds_dst;
   int issue_grp, issue_slot;
@@ -66,8 +76,8 @@ struct RingT {
   int cp[LEAD - 2];    // ... and in the LEAD - 2 intervals before it (cp[0] the newest)
 };
 
-template <int LEAD>
-__device__ __forceinline__ void ringt_issue(RingT<LEAD>& r) {
+template <class RING>
+__device__ __forceinline__ void ringt_issue(RING& r) {
   const char* g = r.src + (size_t)r.issue_grp * RING_GROUP_BYTES;
   const unsigned d = __builtin_amdgcn_readfirstlane(r.lds_dst + (unsigned)r.issue_slot * RING_GROUP_BYTES);
 #pragma unroll
@@ -75,7 +85,7 @@ __device__ __forceinline__ void ringt_issue(RingT<LEAD>& r) {
   int n = r.issue_grp + 1;
   n = (n == r.e0) ? r.j0 : ((n == r.e1) ? r.j1 : n);
   r.issue_grp = n;
-  r.issue_slot = (r.issue_slot + 1 == RingT<LEAD>::SLOTS) ? 0 : r.issue_slot + 1;
+  r.issue_slot = (r.issue_slot + 1 == RING::SLOTS) ? 0 : r.issue_slot + 1;
 }
 
 // s_waitcnt vmcnt(n) with a wave-uniform n that the fully unrolled GEMMs fold to a constant almost everywhere (the field is an
@@ -94,8 +104,9 @@ __device__ __forceinline__ void wait_vm(int n) {
 // in the in-order vmcnt queue sit the counted stores of the last LEAD - 1 intervals and the DMA of LEAD - 2 boundaries:
 // "at most that many outstanding" = that DMA (and everything older) has landed.  Uncounted operations (per-sample loads /
 // stores the compiler issues on its own) only make the wait stricter.
-template <int LEAD>
-__device__ __forceinline__ void ringt_sync(RingT<LEAD>& r) {
+template <class RING>
+__device__ __forceinline__ void ringt_sync(RING& r) {
+  constexpr int LEAD = RING::kLead;
   int n = r.c0 + RT_PPW * (LEAD - 2);
 #pragma unroll
   for (int i = 0; i < LEAD - 2; ++i) n += r.cp[i];
@@ -107,13 +118,13 @@ __device__ __forceinline__ void ringt_sync(RingT<LEAD>& r) {
   r.cp[0] = r.c0;
   r.c0 = 0;
   r.rd_cur = r.rd_next;
-  r.next_slot = (r.next_slot + 1 == RingT<LEAD>::SLOTS) ? 0 : r.next_slot + 1;
+  r.next_slot = (r.next_slot + 1 == RING::SLOTS) ? 0 : r.next_slot + 1;
   r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
 }
 
 // acc[b][p] += W-fragment(i) * X[kk][p]; `hook(group)` runs right behind every group boundary (the kernels put their row stores there)
-template <int NBO, int KS, int XN, int LEAD, class HOOK>
-__device__ __forceinline__ void gemm_t(f32x4 (&acc)[NBO][2], const bf16x8 (&X)[XN][2], RingT<LEAD>& r, bf16x8 (&W)[RING_FIFO],
+template <int NBO, int KS, int XN, class RING, class HOOK>
+__device__ __forceinline__ void gemm_t(f32x4 (&acc)[NBO][2], const bf16x8 (&X)[XN][2], RING& r, bf16x8 (&W)[RING_FIFO],
                                        const char* smem, HOOK&& hook) {
   static_assert((NBO * KS) % RSN_RING_GROUP_FRAGS == 0 && KS <= XN, "a GEMM is a whole number of ring groups");
   // (two nested loops, not one with `if (i % 16 == 0)`: hipcc prices the unrolled size BEFORE it folds the wait's if-chain, and
@@ -160,8 +171,8 @@ __device__ __forceinline__ RowD rowd(const void* base, long long byte_off, int r
   return d;
 }
 // (RSN_RT_*: timing ablations of tools/bf16_train_ab.sh -- wrong results by construction; they compile only under -DRSN_DIAG_BUILD)
-template <int LEAD>
-__device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff, const bf16x8 v, RingT<LEAD>& r) {
+template <class RING>
+__device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff, const bf16x8 v, RING& r) {
 #ifndef RSN_RT_NO_STORES
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, v), d.r, voff, soff, RT_STORE_AUX);
 #ifndef RSN_RT_UNCOUNTED
@@ -169,8 +180,8 @@ __device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff
 #endif
 #endif
 }
-template <int LEAD>
-__device__ __forceinline__ void st8(const RowD& d, unsigned voff, unsigned soff, unsigned w0, unsigned w1, RingT<LEAD>& r) {
+template <class RING>
+__device__ __forceinline__ void st8(const RowD& d, unsigned voff, unsigned soff, unsigned w0, unsigned w1, RING& r) {
 #ifndef RSN_RT_NO_STORES
   const u32x2t v = {w0, w1};
   __builtin_amdgcn_raw_buffer_store_b64(v, d.r, voff, soff, 0);
@@ -302,9 +313,10 @@ __device__ __forceinline__ TileJobs tile_space(const JOBS& J) {
   return t;
 }
 
-template <int LEAD>
-__device__ __forceinline__ void ring_start(RingT<LEAD>& r, const float* pk, const RsnPackedLayout& L, const char* smem, int wid, int lane,
+template <class RING>
+__device__ __forceinline__ void ring_start(RING& r, const float* pk, const RsnPackedLayout& L, const char* smem, int wid, int lane,
                                            int first, int e0, int j0, int e1, int j1, bf16x8 (&Wf)[RING_FIFO]) {
+  constexpr int LEAD = RING::kLead, STAG = RING::kStag;
   r.src = reinterpret_cast<const char*>(pk + L.q_stream) + wid * (RT_PPW * 1024);
   r.lane16 = (unsigned)lane * 16u;
   r.lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wid * (RT_PPW * 1024u);
@@ -312,9 +324,12 @@ __device__ __forceinline__ void ring_start(RingT<LEAD>& r, const float* pk, cons
   r.issue_slot = 0;
   r.e0 = e0; r.j0 = j0; r.e1 = e1; r.j1 = j1;
   r.rd_base = (unsigned)lane * 16u;
-  r.next_slot = 0;
-  r.rd_next = r.rd_base;
-  r.rd_cur = r.rd_base;
+  // group g lives in slot g mod SLOTS.  A late wave (wid >= 4) makes STAG group boundaries without consuming anything first: its
+  // read pointers start STAG slots "before" slot 0, so that its first real boundary finds them where an early wave's start
+  const bool late = STAG > 0 && wid >= 4;
+  r.next_slot = late ? RING::SLOTS - STAG : 0;
+  r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
+  r.rd_cur = r.rd_next;
   r.c0 = 0;
 #pragma unroll
   for (int i = 0; i < LEAD - 2; ++i) r.cp[i] = 0;
@@ -322,15 +337,28 @@ __device__ __forceinline__ void ring_start(RingT<LEAD>& r, const float* pk, cons
 #pragma unroll
   for (int gq = 0; gq < LEAD; ++gq) ringt_issue(r);
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RT_PPW * (LEAD - 1)) : "memory");
+  if (late) {
+#pragma unroll
+    for (int i = 0; i < STAG; ++i) ringt_sync(r);
+  }
 #pragma unroll
   for (int j = 0; j < RING_FIFO; ++j) Wf[j] = *reinterpret_cast<const bf16x8*>(smem + r.rd_next + j * 1024);
+}
+// the early waves' matching boundaries at the end of the kernel (every wave passes the same number of barriers)
+template <class RING>
+__device__ __forceinline__ void ring_finish(RING& r, int wid) {
+  if (RING::kStag > 0 && wid < 4) {
+#pragma unroll
+    for (int i = 0; i < RING::kStag; ++i) ringt_sync(r);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
 // ================================================================================================ training forward
 template <bool NORMALS>
 __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const FieldJobs J) {
   constexpr int W = 256;
-  constexpr int RB = RT_RING_BYTES(RT_LEAD_FWD);
+  constexpr int RB = RT_RING_BYTES(RT_LEAD_FWD, RT_STAG_FWD);
   __shared__ __attribute__((aligned(1024))) char smem[RB + 8 * R16_STASH_BYTES + RT_TABLE_FLOATS * 4];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -354,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
   if (threadIdx.x < 32) bias[RING_MAX_LAYERS * 256 + 288 + 128 + threadIdx.x] = pk[P.L.b_rgb + threadIdx.x];
   if (threadIdx.x < 256) bias[RING_BIAS_FLOATS + threadIdx.x] = pk[P.L.v_density + threadIdx.x];
 
-  RingT<RT_LEAD_FWD> r;
+  RingT<RT_LEAD_FWD, RT_STAG_FWD> r;
   bf16x8 Wf[RING_FIFO];
   // the walk: forward stream [0, q_groups); with the normal sweep then [t_g_trunk, t_g_end) of the transposed stream; again
   ring_start(r, pk, P.L, smem, wid, lane, 0, P.L.q_groups, NORMALS ? P.L.t_g_trunk : 0, NORMALS ? P.L.t_g_end : -1, 0, Wf);
@@ -710,14 +738,14 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+  ring_finish(r, wid);
 }
 
 // ================================================================================================ backward sweep
 template <bool INPUT>
 __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJobs J) {
   constexpr int W = 256;
-  __shared__ __attribute__((aligned(1024))) char smem[RT_RING_BYTES(RT_LEAD_BWD)];
+  __shared__ __attribute__((aligned(1024))) char smem[RT_RING_BYTES(RT_LEAD_BWD, RT_STAG_BWD)];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const BwdShared& P = J.s;
@@ -726,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
   const float* __restrict__ pk = P.packed;
   const int L = P.num_layers;
 
-  RingT<RT_LEAD_BWD> r;
+  RingT<RT_LEAD_BWD, RT_STAG_BWD> r;
   bf16x8 Wf[RING_FIFO];
   // the walk: the whole transposed stream; without an input gradient the two encoded-input pieces are jumped over
   {
@@ -976,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ring_finish(r, wid);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

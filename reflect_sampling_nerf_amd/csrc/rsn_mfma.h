@@ -129,6 +129,11 @@ __device__ __forceinline__ void put4(float* save, int off, const float4 v) {
 // [N, row_elems] buffer (base = the tile's first row, wave-uniform), the lane sends one 32-bit offset (its row + 16 h
 // bytes) and the (block, q) position is a scalar offset.  Lanes past the last valid row fall outside the descriptor's
 // range and the hardware drops their stores: no per-lane null pointers, no exec-masked branches around the stores.
+// cache policy of the saved-row buffer stores (aux bits: 2 = nt); A/B switch of tools/ (default policy measured best for the
+// per-wave-stream kernels in round 3; the LDS-ring bf16 training kernels use nt, rsn_field_bf16_train.hip)
+#ifndef RSN_SAVED_ROW_AUX
+#define RSN_SAVED_ROW_AUX 0
+#endif
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct RowBuf {
@@ -163,17 +168,17 @@ template <bool SBF>
 __device__ __forceinline__ void sv_put(const RowBuf& b, int nb, int q, int, const float4 v) {
   if (SBF) {
     const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), b.r, b.voff, (nb * 4 + q) * 16, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), b.r, b.voff, (nb * 4 + q) * 16, RSN_SAVED_ROW_AUX);
   } else {
     const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (nb * 4 + q) * 32, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (nb * 4 + q) * 32, RSN_SAVED_ROW_AUX);
   }
 }
 // the float4 of K-iteration `it` of the lane's row (features it*8 + 4h ..): the same bytes sv_put(nb = it/4, q = it%4) writes
 __device__ __forceinline__ void sv_put_it(const float*, int, const float4) {}
 __device__ __forceinline__ void sv_put_it(const RowBuf& b, int it, const float4 v) {
   const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-  if ((unsigned)it * 32u < b.lim) __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (unsigned)it * 32u, 0);  // wave-uniform
+  if ((unsigned)it * 32u < b.lim) __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (unsigned)it * 32u, RSN_SAVED_ROW_AUX);  // wave-uniform
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -245,20 +245,25 @@ class ReflectSamplingNeRFNerfField(Field):
         return level
 
     def evaluate_reflect_train(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid_bins: Tensor,
-                               n_dev: Tensor, sqradius: Tensor, work: Optional[Dict] = None):
+                               n_dev: Tensor, sqradius: Tensor, work: Optional[Dict] = None,
+                               inf_directions: Optional[Tensor] = None):
         """The first two field evaluations of the reflect branch in ONE launch (rsn_field_forward_train_jobs): the
         reflect-coarse level on the reflected rays (model.py:292-296) and get_inf_color of the same rays (model.py:290,
         field.py:190-201).  Both depend only on the secondary rays; as jobs of one launch get_inf_color's few tiles fill
         the level's last, partial round of tiles instead of occupying a launch of their own.
         -> (level dict as evaluate_frustums_train(want_normals=False), inf rgb [R,3], inf saved)."""
         lib = _abi.load_library()
-        R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
+        R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1  # R here: the rays the LEVEL is sized for
+        # get_inf_color runs on ALL secondary rays (`inf_directions` / sqradius may be longer than the level's inputs when the
+        # level's capacity is below the batch size: train_graph.reflect_capacity)
+        d_inf = directions if inf_directions is None else inf_directions
+        R_inf = d_inf.shape[0]
         dev = origins.device
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         level = {"sigma": f(R, S), "color": f(R, S, 3), "pred_normals": f(R, S, 3), "n_dot_d": f(R, S),
                  "diff": f(R, S, 3), "tint": f(R, S, 3), "roughness": f(R, S), "raw_density": f(R, S)}
-        saved, inf_saved = self.alloc_saved(R * S, dev), self.alloc_saved(R, dev)
-        bg = f(R, 3)
+        saved, inf_saved = self.alloc_saved(R * S, dev), self.alloc_saved(R_inf, dev)
+        bg = f(R_inf, 3)
         fo = ops.field_outputs_struct(level)
         fs, fs_inf = FieldSaved(), FieldSaved()
         for k, v in saved.items():
@@ -270,8 +275,8 @@ class ReflectSamplingNeRFNerfField(Field):
         jobs[0].origins, jobs[0].directions = origins.data_ptr(), directions.data_ptr()
         jobs[0].pixel_area, jobs[0].euclid_bins = pixel_area.data_ptr(), euclid_bins.data_ptr()
         jobs[0].out, jobs[0].saved = C.pointer(fo), C.pointer(fs)
-        jobs[1].kind, jobs[1].n_rays, jobs[1].n_dev, jobs[1].n_samples = 1, R, n_dev.data_ptr(), 1
-        jobs[1].directions, jobs[1].sqradius, jobs[1].out_rgb = directions.data_ptr(), sqradius.data_ptr(), bg.data_ptr()
+        jobs[1].kind, jobs[1].n_rays, jobs[1].n_dev, jobs[1].n_samples = 1, R_inf, n_dev.data_ptr(), 1
+        jobs[1].directions, jobs[1].sqradius, jobs[1].out_rgb = d_inf.data_ptr(), sqradius.data_ptr(), bg.data_ptr()
         jobs[1].saved = C.pointer(fs_inf)
         desc = self.field_desc()
         pk = self.packed_weights()

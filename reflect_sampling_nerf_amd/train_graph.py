@@ -282,24 +282,25 @@ def _field_backward(field, rays, eb, level, gin: Dict[str, Optional[Tensor]], ne
     return gout
 
 
-def _reflect_field_backward(field, rays2, sq, levels, inf_saved, g_bg, n_dev, R: int):
+def _reflect_field_backward(field, rays2, sq, levels, inf_saved, g_bg, n_dev, R: int, Rb: Optional[int] = None):
     """The three backward sweeps of the reflect branch in ONE launch (rsn_field_backward_jobs): the two reflect levels
     (`levels`: [(euclid bins, level dict, upstream colour gradient, S)]) and get_inf_color (upstream: g_bg, the background
     gradient both levels' compositing backward accumulated).  -> ([gout per level], gout of get_inf_color)."""
     lib = _abi.load_library()
     o, d, pa = rays2
     dev = o.device
+    Rb = R if Rb is None else Rb  # the levels' capacity (their buffers hold Rb rays); get_inf_color stays at R
     keep = []  # ctypes structures the job table points into
     jobs = (_abi.FieldBwdJob * (len(levels) + 1))()
     gouts, dev_work = [], []
     for k, (eb, lv, g_color, S) in enumerate(levels):
-        gout, gst = _alloc_gout(field, R * S, dev, True)
+        gout, gst = _alloc_gout(field, Rb * S, dev, True)
         gi = FieldGradsIn()
         gi.color = ptr(g_color)
         fo, fs = ops.field_outputs_struct(lv), _saved_struct(lv["saved"])
         keep += [gst, gi, fo, fs]
         j = jobs[k]
-        j.kind, j.n_rays, j.n_dev, j.n_samples, j.need_input_grad = 0, R, n_dev.data_ptr(), S, 1
+        j.kind, j.n_rays, j.n_dev, j.n_samples, j.need_input_grad = 0, Rb, n_dev.data_ptr(), S, 1
         j.origins, j.directions, j.pixel_area, j.euclid_bins = o.data_ptr(), d.data_ptr(), pa.data_ptr(), eb.data_ptr()
         j.fwd, j.saved, j.gin, j.gout = C.pointer(fo), C.pointer(fs), C.pointer(gi), C.pointer(gst)
         gouts.append(gout)
@@ -330,6 +331,57 @@ def _ray_sum(x: Tensor, n: int, S: int, n_dev=None) -> Tensor:
 from .ops import LazyOutputs  # noqa: E402,F401  (kept importable from here)
 
 _LazyAux = LazyOutputs
+
+
+# ------------------------------------------------------------------------------------------------ reflect-branch capacity
+def reflect_capacity(model, R: int, dev) -> int:
+    """Rays the two reflect LEVELS of a training step are sized for (their saved activations and layer gradients are ~20 KB
+    per sample in fp32, 64 + 64 samples per ray: 10.6 GB at 4096 rays -- a third of the step's memory).
+
+    Default (`model.reflect_capacity is None`): R, whatever the number M of reflected rays turns out to be -- M lives on the
+    device and the host never reads it, so only R is a safe bound.  `model.reflect_capacity = "auto"` (opt-in) sizes them for
+    the PREVIOUS steps' count instead: every step copies its device-side M into pinned host memory behind the reflect setup
+    (asynchronously, no wait); the next step's forward looks at the newest copy whose event has fired (one step old: it fired
+    long ago, no stall) and takes cap = min(R, 1.25 M + 128, rounded up to 64).  The level launches clamp the device count to
+    their capacity, so a step whose M exceeds it (M jumps by more than 25 % from one step to the next) renders and trains the
+    reflect branch on its first `cap` reflected rays only -- detected one step late (`model.reflect_overflows` counts, a
+    warning is logged, and the capacity falls back to R for the rest of the run).  That one truncated step is why this is
+    opt-in: the default is exact on every step."""
+    mode = getattr(model, "reflect_capacity", None)
+    st = model.__dict__.setdefault("_reflect_cap_state", {"pending": [], "m_seen": None, "disabled": False, "overflows": 0})
+    if mode is None or st["disabled"] or dev.type != "cuda":
+        return R
+    while st["pending"] and st["pending"][0][0].query():  # counts whose copy has landed: newest wins; check each against its cap
+        _ev, host, cap_used, r_used = st["pending"].pop(0)
+        m = int(host[0])
+        st["m_seen"] = m
+        if m > cap_used:
+            st["overflows"] += 1
+            model.reflect_overflows = st["overflows"]
+            st["disabled"] = True
+            import warnings
+
+            warnings.warn(f"reflect_capacity='auto': a step reflected {m} rays with buffers for {cap_used} (of {r_used}); its "
+                          "reflect branch ran on the first rays only.  Falling back to full-size buffers.")
+            return R
+    if st["m_seen"] is None:
+        return R
+    cap = (int(st["m_seen"] * 1.25) + 128 + 63) // 64 * 64
+    return max(64, min(R, cap))
+
+
+def _note_reflect_count(model, nm: Tensor, cap: int, R: int) -> None:
+    """Asynchronous copy of this step's device-side reflected-ray count for reflect_capacity() of a later step (opt-in mode only)."""
+    if getattr(model, "reflect_capacity", None) is None or not nm.is_cuda:
+        return
+    st = model.__dict__["_reflect_cap_state"]
+    if st["disabled"] or len(st["pending"]) > 8:
+        return
+    host = torch.empty(1, dtype=nm.dtype, pin_memory=True)
+    host.copy_(nm, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(nm.device))
+    st["pending"].append((ev, host, cap, R))
 
 
 # ------------------------------------------------------------------------------------------------ the autograd node
@@ -372,7 +424,9 @@ class GetOutputsTrain(torch.autograd.Function):
             ORIGINAL ray [R, S+1] -- the rows of this pass's reflected rays are used -- or per reflected ray [n_valid, S+1]."""
             t = jitter.get(name)
             if t is None:
-                return torch.rand(n, S + 1, device=dev)
+                # (a level sized below R -- reflect_capacity -- takes the first rows of the same R-row draw: the random stream of
+                # a step does not depend on the capacity)
+                return torch.rand(n, S + 1, device=dev) if (rows is None or n == R) else torch.rand(R, S + 1, device=dev)[:n]
             t = ops._f32c(t.to(dev))
             if rows is not None and t.shape[0] == R and n_valid != R:
                 t = t[rows[:n_valid].long()].contiguous()
@@ -413,23 +467,29 @@ class GetOutputsTrain(torch.autograd.Function):
         # injected draws / bins come in the reference's shapes ([M, S + 1]): that (test) mode reads M first.  The
         # production path never does: M stays on the device for the whole step -- forward, backward, weight gradients.
         M = int(nm.item()) if (jitter or bins) else None
+        # Rb: rays the reflect LEVELS are sized / launched for (R unless model.reflect_capacity = "auto": see reflect_capacity);
+        # the per-ray quantities of the branch (secondary rays, get_inf_color, background) stay at R
+        Rb = R if M is not None else reflect_capacity(model, R, dev)
+        if M is None:
+            _note_reflect_count(model, nm, Rb, R)
         o2, d2, pa2, sq = rs["origins2"], rs["directions2"], rs["pixel_area2"], rs["sqradius"]
         near2, far2 = rs["nears2"], rs["fars2"]
+        o2b, d2b, pa2b, near2b, far2b = o2[:Rb], d2[:Rb], pa2[:Rb], near2[:Rb], far2[:Rb]
         # reflect-coarse level and get_inf_color (the composites' background, model.py:290): both depend only on the
         # secondary rays and run as two jobs of ONE launch (rsn_field_forward_train_jobs)
         # launches sized for R rays do the work of M: the timer resolves the device-side count when it reads its events
         work_rc, work_rf = ({"points": 0, "points_dev": [(nm, k)]} for k in (Src + 1, Srf))
-        sb_rc, eb_rc = level_bins("reflect_coarse", R, Src, lambda: ops.sample_spaced(
-            R, nm, Src, rec.spacing, rec.tan, near2, far2, jit("reflect_coarse", R, Src, rs["ray_index"], M)), M)
-        lrc, bg, inf_saved = fld.evaluate_reflect_train(o2, d2, pa2, eb_rc, nm, sq, work=work_rc)
-        crc = ops.composite(R, nm, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
-        ops.reflect_combine(R, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
-        sb_rf, eb_rf = level_bins("reflect_fine", R, Srf, lambda: ops.sample_pdf(
-            R, nm, Src, Srf, rec.spacing, rec.tan, model.sampler_reflect_pdf.histogram_padding, near2, far2,
-            crc["weights"], sb_rc, jit("reflect_fine", R, Srf, rs["ray_index"], M)), M)
-        lrf = fld.evaluate_frustums_train(o2, d2, pa2, eb_rf, n_dev=nm, want_normals=False, work=work_rf)
-        crf = ops.composite(R, nm, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
-        ops.reflect_combine(R, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
+        sb_rc, eb_rc = level_bins("reflect_coarse", Rb, Src, lambda: ops.sample_spaced(
+            Rb, nm, Src, rec.spacing, rec.tan, near2b, far2b, jit("reflect_coarse", Rb, Src, rs["ray_index"], M)), M)
+        lrc, bg, inf_saved = fld.evaluate_reflect_train(o2b, d2b, pa2b, eb_rc, nm, sq, work=work_rc, inf_directions=d2)
+        crc = ops.composite(Rb, nm, Src, 2, 0, lrc["sigma"], eb_rc, lrc["color"], bg_rgb=bg, want_depth=False)
+        ops.reflect_combine(Rb, nm, rs["ray_index"], cf["diff"], cf["tint"], crc["rgb"], rs["reflect_coarse"])
+        sb_rf, eb_rf = level_bins("reflect_fine", Rb, Srf, lambda: ops.sample_pdf(
+            Rb, nm, Src, Srf, rec.spacing, rec.tan, model.sampler_reflect_pdf.histogram_padding, near2b, far2b,
+            crc["weights"], sb_rc, jit("reflect_fine", Rb, Srf, rs["ray_index"], M)), M)
+        lrf = fld.evaluate_frustums_train(o2b, d2b, pa2b, eb_rf, n_dev=nm, want_normals=False, work=work_rf)
+        crf = ops.composite(Rb, nm, Srf, 2, 0, lrf["sigma"], eb_rf, lrf["color"], bg_rgb=bg)
+        ops.reflect_combine(Rb, nm, rs["ray_index"], cf["diff"], cf["tint"], crf["rgb"], rs["reflect_fine"])
         mask_bool = rs["mask"].bool()
         model._last_n_masked_dev = nm  # device-side; `model._last_num_reflected` reads it on demand (a host sync)
 
@@ -446,7 +506,7 @@ class GetOutputsTrain(torch.autograd.Function):
             aux.lazy["depth_reflect_fine"] = (nm, crf["depth"])
         elif M > 0:  # the count is on the host already (injected draws / bins)
             aux["depth_reflect_fine"] = crf["depth"][:M].unsqueeze(-1)
-        st = dict(R=R, eb_c=eb_c, eb_f=eb_f, lc=lc, lf=lf, cc=cc, cf=cf, rs=rs, rays=(o, d, pa),
+        st = dict(R=R, Rb=Rb, eb_c=eb_c, eb_f=eb_f, lc=lc, lf=lf, cc=cc, cf=cf, rs=rs, rays=(o, d, pa),
                   rays2=(o2, d2, pa2), sq=sq, bg=bg, inf_saved=inf_saved, eb_rc=eb_rc, eb_rf=eb_rf, lrc=lrc, lrf=lrf,
                   crc=crc, crf=crf)
         if getattr(model, "_keep_train_state", False):  # test hook: the sample positions this pass evaluated
@@ -494,23 +554,24 @@ class GetOutputsTrain(torch.autograd.Function):
         # the weight-gradient kernel takes the first M (x samples) rows of each reflect evaluation by the same count.  With
         # M = 0 every launch below is a no-op on the device: no host-side early-out, no host read.
         nm = rs["n_masked"]
+        Rb = st["Rb"]  # rays the two reflect levels were sized for (R by default; forward)
         g_bg = torch.zeros(R, 3, device=dev)
         g_pa2 = torch.zeros(R, device=dev)
         jobs = []
         for eb, lv, cp, g_out, S in ((st["eb_rf"], st["lrf"], st["crf"], g_refl_f, Srf),
                                      (st["eb_rc"], st["lrc"], st["crc"], g_refl_c, Src)):
-            g_comp = torch.empty(R, 3, device=dev)
-            check(lib.rsn_reflect_combine_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(cf["diff"]), ptr(cf["tint"]),
+            g_comp = torch.empty(Rb, 3, device=dev)
+            check(lib.rsn_reflect_combine_backward(Rb, ptr(nm), ptr(rs["ray_index"]), ptr(cf["diff"]), ptr(cf["tint"]),
                                                    ptr(cp["rgb"]), ptr(g_out), ptr(g_comp), ops._stream()))
-            cb = _composite_backward(R, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
+            cb = _composite_backward(Rb, S, 2, 0, 1, lv, eb, cp["weights"], g_comp, bg=st["bg"], want_sigma=False,
                                      want_bg=True, n_dev=nm)
-            g_bg += cb["g_bg"]
+            g_bg[:Rb] += cb["g_bg"]
             jobs.append((eb, lv, cb["g_color"], S))
         # the sweeps of both levels and of get_inf_color (whose upstream gradient g_bg is complete now) in ONE launch:
         # their tiles share the persistent workgroups' rounds (rsn_field_backward_jobs)
-        gouts, gout = _reflect_field_backward(fld, st["rays2"], st["sq"], jobs, st["inf_saved"], g_bg, nm, R)
+        gouts, gout = _reflect_field_backward(fld, st["rays2"], st["sq"], jobs, st["inf_saved"], g_bg, nm, R, Rb)
         for (eb, lv, _g, S), go in zip(jobs, gouts):
-            g_pa2 += _ray_sum(go["d_input"], R, S, nm)
+            g_pa2[:Rb] += _ray_sum(go["d_input"], Rb, S, nm)
             pending.append((lv["saved"], go, True, (nm, S)))
         pending.append((st["inf_saved"], gout, False, (nm, 1)))
         g_r = torch.empty(R, device=dev)  # the kernel zero-fills the rays that are not reflected

@@ -1337,6 +1337,66 @@ def test_training_step_issues_no_device_to_host_read(dev):
     assert outputs["depth_reflect_fine"].shape == (M, 1) and "depth_reflect_fine" in outputs.keys()
 
 
+def test_reflect_capacity_auto_equals_full_size_buffers(dev):
+    """Opt-in `model.reflect_capacity = "auto"` (train_graph.reflect_capacity): the two reflect levels -- a third of the step's
+    memory -- are sized for 1.25 x the PREVIOUS step's reflected-ray count (copied to pinned memory asynchronously, looked at one
+    step late: still no device-to-host read in the step) instead of for all R rays.  On a steady batch the step is the default
+    step: same outputs, same gradients (to the order of the weight-gradient atomics), fewer bytes; a step whose count jumps past
+    its capacity is detected one step late, counted, warned about, and the capacity falls back to R."""
+    import warnings
+
+    from reflect_sampling_nerf_amd.parallel import train_step
+
+    R = 704
+    grads, peak = {}, {}
+    for mode in (None, "auto"):
+        model, rb, batch = _train_setup(dev, R, (16, 16, 16, 16), layers=8, width=128, bias_shift=1.0)
+        model.reflect_capacity = mode
+        opt = pkg.FusedRAdam(model.get_param_groups()["fields"], lr=0.0, eps=1e-15)  # lr 0: every step sees the same weights
+        torch.manual_seed(5)
+        for k in range(3):  # step 0 sizes for R; from step 2 on the capacity follows step k - 1's count
+            train_step(model, rb, batch, opt, None, 100 + k)
+            torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            torch.manual_seed(77)
+            train_step(model, rb, batch, opt, None, 110)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        peak[mode] = torch.cuda.max_memory_allocated()
+        grads[mode] = {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None}
+        M = model._last_num_reflected
+        assert 0 < M < 0.7 * R, M
+        if mode == "auto":
+            assert getattr(model, "reflect_overflows", 0) == 0
+            assert abs(model._reflect_cap_state["m_seen"] - M) <= 0.1 * R  # the same rays every step (jitter moves a few)
+            assert model._reflect_cap_state["m_seen"] * 1.25 + 192 < R  # so the levels really were sized below R
+    assert sorted(grads[None]) == sorted(grads["auto"])
+    for n, g0 in grads[None].items():
+        assert float((grads["auto"][n] - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12, n
+    assert peak["auto"] < peak[None]
+    # overflow: a model that reflected few rays is handed a batch that reflects many
+    model, rb, batch = _train_setup(dev, R, (16, 16, 16, 16), layers=8, width=128, bias_shift=1.0)
+    model.reflect_capacity = "auto"
+    opt = pkg.FusedRAdam(model.get_param_groups()["fields"], lr=0.0, eps=1e-15)
+    train_step(model, rb, batch, opt, None, 100)
+    torch.cuda.synchronize()
+    model._reflect_cap_state["pending"].clear()
+    model._reflect_cap_state["m_seen"] = 1  # as if the previous steps had reflected a single ray: capacity 192 < M
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        train_step(model, rb, batch, opt, None, 101)   # truncated step
+        torch.cuda.synchronize()
+        train_step(model, rb, batch, opt, None, 102)   # detects it, falls back
+        torch.cuda.synchronize()
+    M = model._last_num_reflected
+    if M > 192:  # (capacity of m_seen = 1: 1.25 + 128 rounded up to 64 = 192)
+        assert model.reflect_overflows == 1 and model._reflect_cap_state["disabled"]
+        assert any("reflect_capacity" in str(x.message) for x in w)
+
+
 def test_train_step_without_reflected_rays(dev):
     """M == 0 in TRAINING mode (the reference returns early, model.py:259-260): every reflect launch runs on a device-side
     count of zero, backward included.  Reflect colours are white * (1 - acc_fine) (model.py:240-241), every parameter
