@@ -54,6 +54,17 @@
 #ifndef RT_STAG_BWD
 #define RT_STAG_BWD 0
 #endif
+// which waves run behind (the partner of a wave on its SIMD must be in the other set)
+#ifndef RT_LATE_MODE
+#define RT_LATE_MODE 0
+#endif
+#if RT_LATE_MODE == 0
+#define RT_LATE_WAVE(wid) ((wid) >= 4)
+#elif RT_LATE_MODE == 1
+#define RT_LATE_WAVE(wid) (((wid) & 1) != 0)
+#else
+#define RT_LATE_WAVE(wid) ((((wid) >> 1) & 1) != 0)
+#endif
 #define RT_PPW (RSN_RING_GROUP_FRAGS / 8)
 #define RT_TABLE_FLOATS (RING_BIAS_FLOATS + 256)   // biases (packed row order) + the density-head row (normal-sweep seed)
 #define RT_RING_BYTES(LEAD, STAG) (((LEAD) + (STAG) + 1) * RING_GROUP_BYTES)
@@ -326,7 +337,7 @@ __device__ __forceinline__ void ring_start(RING& r, const float* pk, const RsnPa
   r.rd_base = (unsigned)lane * 16u;
   // group g lives in slot g mod SLOTS.  A late wave (wid >= 4) makes STAG group boundaries without consuming anything first: its
   // read pointers start STAG slots "before" slot 0, so that its first real boundary finds them where an early wave's start
-  const bool late = STAG > 0 && wid >= 4;
+  const bool late = STAG > 0 && RT_LATE_WAVE(wid);
   r.next_slot = late ? RING::SLOTS - STAG : 0;
   r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
   r.rd_cur = r.rd_next;
@@ -347,7 +358,7 @@ __device__ __forceinline__ void ring_start(RING& r, const float* pk, const RsnPa
 // the early waves' matching boundaries at the end of the kernel (every wave passes the same number of barriers)
 template <class RING>
 __device__ __forceinline__ void ring_finish(RING& r, int wid) {
-  if (RING::kStag > 0 && wid < 4) {
+  if (RING::kStag > 0 && !RT_LATE_WAVE(wid)) {
 #pragma unroll
     for (int i = 0; i < RING::kStag; ++i) ringt_sync(r);
   }
@@ -478,10 +489,11 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
     }
 
     // saved-row descriptors of this tile (scalar)
-    const RowD d_enc = rowd(a.saved.enc, (long long)p0 * 256, rows, 256);      // bf16 [N,128]
-    const RowD d_sh = rowd(a.saved.sh, (long long)p0 * 128, rows, 128);        // bf16 [N,64]
-    const RowD d_bott = rowd(a.saved.bott, (long long)p0 * 512, rows, 512);    // bf16 [N,256]
-    const RowD d_hid = rowd(a.saved.hid, (long long)p0 * 256, rows, 256);      // bf16 [N,128]
+    // (built where they are used: four scalar registers each, and the kernel is short of those too)
+    auto mk_enc = [&]() { return rowd(a.saved.enc, (long long)p0 * 256, rows, 256); };      // bf16 [N,128]
+    auto mk_sh = [&]() { return rowd(a.saved.sh, (long long)p0 * 128, rows, 128); };        // bf16 [N,64]
+    auto mk_bott = [&]() { return rowd(a.saved.bott, (long long)p0 * 512, rows, 512); };    // bf16 [N,256]
+    auto mk_hid = [&]() { return rowd(a.saved.hid, (long long)p0 * 256, rows, 256); };      // bf16 [N,128]
     auto d_act = [&](int l) { return rowd(a.saved.act, ((long long)l * n_max + p0) * 512, rows, 512); };
     auto d_bits = [&](int l) { return rowd(a.saved.relu_bits, ((long long)l * n_max + p0) * 32, rows, 32); };
 
@@ -493,6 +505,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
       init_acc16<16>(acc, bias, g);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) { X[kk][0] = ST[(kk * 2) * 64]; X[kk][1] = ST[(kk * 2 + 1) * 64]; }
+      const RowD d_enc = mk_enc();
       gemm_t<16, 4, 8>(acc, X, r, Wf, smem, [&](int gi) {  // the encoded inputs leave while layer 0 reads them
         st16(d_enc, vrow[0] * 256 + 16 * g, gi * 64, X[gi][0], r);
         st16(d_enc, vrow[1] * 256 + 16 * g, gi * 64, X[gi][1], r);
@@ -617,6 +630,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
       bf16x8 XS[2][2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) { XS[kk][0] = ST[(kk * 2) * 64]; XS[kk][1] = ST[(kk * 2 + 1) * 64]; }
+      const RowD d_sh = mk_sh(), d_bott = mk_bott();
       gemm_t<8, 2, 2>(accm, XS, r, Wf, smem, [&](int) {  // the SH inputs' rows
         st16(d_sh, vrow[0] * 128 + 16 * g, 0, XS[0][0], r);
         st16(d_sh, vrow[1] * 128 + 16 * g, 0, XS[0][1], r);
@@ -642,7 +656,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
 #pragma unroll
         for (int b = 1; b < 4; ++b) { accr[b][0] = z; accr[b][1] = z; }
       }
-      const RowD db = d_bits(L);
+      const RowD db = d_bits(L), d_hid = mk_hid();
       gemm_t<4, 4, 8>(accr, X, r, Wf, smem, [&](int) {  // the mid hidden rows and bits
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -696,6 +710,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
       }
       float part[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, raw[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
       auto enc_part = [&]() {  // eacc = (encoded-input part)^T x gradient, folded at once with the lane's saved features
+        const RowD d_enc = mk_enc();
         bf16x8 ft[4][2];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
