@@ -133,10 +133,14 @@ __device__ __forceinline__ void ringt_sync(RING& r) {
   r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
 }
 
-// acc[b][p] += W-fragment(i) * X[kk][p]; `hook(group)` runs right behind every group boundary (the kernels put their row stores there)
-template <int NBO, int KS, int XN, class RING, class HOOK>
+// acc[b][p] (+)= W-fragment(i) * X[kk][p]; `hook(group)` runs right behind every group boundary (the kernels put their row stores
+// there).  INIT: how the accumulators start -- GI_ACC: they are live (a second GEMM onto the same accumulators); GI_ZERO / GI_BIAS:
+// the FIRST K-step's MFMAs take the constant 0 / the bias row (LDS table, packed row order; the same vector for both points) as their
+// C operand, so no accumulator is written before its first MFMA: 128 v_mov per layer and wave gone (a fifth of the hand-off's VALU).
+enum { GI_ACC = 0, GI_ZERO = 1, GI_BIAS = 2 };
+template <int NBO, int KS, int XN, int INIT, class RING, class HOOK>
 __device__ __forceinline__ void gemm_t(f32x4 (&acc)[NBO][2], const bf16x8 (&X)[XN][2], RING& r, bf16x8 (&W)[RING_FIFO],
-                                       const char* smem, HOOK&& hook) {
+                                       const char* smem, HOOK&& hook, const float* bias = nullptr, int g = 0) {
   static_assert((NBO * KS) % RSN_RING_GROUP_FRAGS == 0 && KS <= XN, "a GEMM is a whole number of ring groups");
   // (two nested loops, not one with `if (i % 16 == 0)`: hipcc prices the unrolled size BEFORE it folds the wait's if-chain, and
   // refuses to unroll a 128-iteration body that carries the chain in every iteration -- the accumulators then live in scratch)
@@ -152,8 +156,18 @@ __device__ __forceinline__ void gemm_t(f32x4 (&acc)[NBO][2], const bf16x8 (&X)[X
       const int pos = f + RING_FIFO;
       W[i % RING_FIFO] = *reinterpret_cast<const bf16x8*>(
           smem + (pos < RSN_RING_GROUP_FRAGS ? r.rd_cur + pos * 1024 : r.rd_next + (pos - RSN_RING_GROUP_FRAGS) * 1024));
-      acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][0], acc[b][0], 0, 0, 0);
-      acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][1], acc[b][1], 0, 0, 0);
+      if (INIT != GI_ACC && kk == 0) {
+        f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (INIT == GI_BIAS) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + b * 16 + 4 * g);
+          c = f32x4{bv.x, bv.y, bv.z, bv.w};
+        }
+        acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[0][0], c, 0, 0, 0);
+        acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[0][1], c, 0, 0, 0);
+      } else {
+        acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][0], acc[b][0], 0, 0, 0);
+        acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][1], acc[b][1], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -502,33 +516,32 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
     // ---------------- trunk -----------------
     {
       f32x4 acc[16][2];
-      init_acc16<16>(acc, bias, g);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) { X[kk][0] = ST[(kk * 2) * 64]; X[kk][1] = ST[(kk * 2 + 1) * 64]; }
       const RowD d_enc = mk_enc();
-      gemm_t<16, 4, 8>(acc, X, r, Wf, smem, [&](int gi) {  // the encoded inputs leave while layer 0 reads them
+      gemm_t<16, 4, 8, GI_BIAS>(acc, X, r, Wf, smem, [&](int gi) {  // the encoded inputs leave while layer 0 reads them
         st16(d_enc, vrow[0] * 256 + 16 * g, gi * 64, X[gi][0], r);
         st16(d_enc, vrow[1] * 256 + 16 * g, gi * 64, X[gi][1], r);
-      });
+      }, bias, g);
 #pragma unroll 1
       for (int l = 1; l < L; ++l) {
-        acc_to_x16<16, 8, true, 8>(acc, X, bias + l * 256, g);   // X = act[l-1] (post-ReLU), accumulators <- bias[l]
+        acc_to_x16<16, 8, true, 8>(acc, X);   // X = act[l-1] (post-ReLU)
 #pragma unroll
         for (int p = 0; p < 2; ++p) { bw[p][0] = relu_bits_of<8>(X, p, 0, one2); bw[p][1] = relu_bits_of<8>(X, p, 4, one2); }
         const RowD da = d_act(l - 1), db = d_bits(l - 1);
-        gemm_t<16, 8, 8>(acc, X, r, Wf, smem, [&](int gi) {  // act[l-1] leaves from the GEMM that reads it, one K-step per group
+        gemm_t<16, 8, 8, GI_BIAS>(acc, X, r, Wf, smem, [&](int gi) {  // act[l-1] leaves from the GEMM that reads it, one K-step per group
           st16(da, vrow[0] * 512 + 16 * g, gi * 64, X[gi][0], r);
           st16(da, vrow[1] * 512 + 16 * g, gi * 64, X[gi][1], r);
           if (gi == 0) {
             st8(db, vrow[0] * 32 + 8 * g, 0, bw[0][0], bw[0][1], r);
             st8(db, vrow[1] * 32 + 8 * g, 0, bw[1][0], bw[1][1], r);
           }
-        });
+        }, bias + l * 256, g);
         if (l == P.skip_layer) {
           bf16x8 XE[4][2];
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) { XE[kk][0] = ST[(kk * 2) * 64]; XE[kk][1] = ST[(kk * 2 + 1) * 64]; }
-          gemm_t<16, 4, 4>(acc, XE, r, Wf, smem, NoHook());
+          gemm_t<16, 4, 4, GI_ACC>(acc, XE, r, Wf, smem, NoHook());
         }
       }
       acc_to_x16<16, 8, true, 8>(acc, X);  // out_activation = ReLU: the embedding = act[L-1]
@@ -540,8 +553,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
     float dcol[2][3];
     {
       f32x4 acch[2][2];
-      init_acc16<2>(acch, b_bh + 256, g);
-      gemm_t<2, 8, 8>(acch, X, r, Wf, smem, NoHook());
+      gemm_t<2, 8, 8, GI_BIAS>(acch, X, r, Wf, smem, NoHook(), b_bh + 256, g);
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const float r0 = acch[0][p][0], r1 = acch[0][p][1], r2 = acch[0][p][2], r3 = acch[0][p][3];
@@ -607,16 +619,15 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
     // ---------------- bottleneck (the embedding's rows and the last layer's bits leave from this GEMM) -----------------
     {
       f32x4 acc[16][2];
-      init_acc16<16>(acc, b_bh, g);
       const RowD da = d_act(L - 1), db = d_bits(L - 1);
-      gemm_t<16, 8, 8>(acc, X, r, Wf, smem, [&](int gi) {
+      gemm_t<16, 8, 8, GI_BIAS>(acc, X, r, Wf, smem, [&](int gi) {
         st16(da, vrow[0] * 512 + 16 * g, gi * 64, X[gi][0], r);
         st16(da, vrow[1] * 512 + 16 * g, gi * 64, X[gi][1], r);
         if (gi == 0) {
           st8(db, vrow[0] * 32 + 8 * g, 0, bw[0][0], bw[0][1], r);
           st8(db, vrow[1] * 32 + 8 * g, 0, bw[1][0], bw[1][1], r);
         }
-      });
+      }, b_bh, g);
       acc_to_x16<16, 8, false, 8>(acc, X);  // bottleneck output (no activation): the x-part of mlp_mid's input
     }
 
@@ -626,18 +637,17 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
     for (int p = 0; p < 2; ++p) { bwe[p][0] = bw[p][0]; bwe[p][1] = bw[p][1]; }
     {
       f32x4 accm[8][2];
-      init_acc16<8>(accm, b_mid, g);
       bf16x8 XS[2][2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) { XS[kk][0] = ST[(kk * 2) * 64]; XS[kk][1] = ST[(kk * 2 + 1) * 64]; }
       const RowD d_sh = mk_sh(), d_bott = mk_bott();
-      gemm_t<8, 2, 2>(accm, XS, r, Wf, smem, [&](int) {  // the SH inputs' rows
+      gemm_t<8, 2, 2, GI_BIAS>(accm, XS, r, Wf, smem, [&](int) {  // the SH inputs' rows
         st16(d_sh, vrow[0] * 128 + 16 * g, 0, XS[0][0], r);
         st16(d_sh, vrow[1] * 128 + 16 * g, 0, XS[0][1], r);
         st16(d_sh, vrow[0] * 128 + 16 * g, 64, XS[1][0], r);
         st16(d_sh, vrow[1] * 128 + 16 * g, 64, XS[1][1], r);
-      });
-      gemm_t<8, 8, 8>(accm, X, r, Wf, smem, [&](int gi) {  // the bottleneck rows: two K-steps per group
+      }, b_mid, g);
+      gemm_t<8, 8, 8, GI_ACC>(accm, X, r, Wf, smem, [&](int gi) {  // the bottleneck rows: two K-steps per group
         st16(d_bott, vrow[0] * 512 + 16 * g, (2 * gi) * 64, X[2 * gi][0], r);
         st16(d_bott, vrow[1] * 512 + 16 * g, (2 * gi) * 64, X[2 * gi][1], r);
         st16(d_bott, vrow[0] * 512 + 16 * g, (2 * gi + 1) * 64, X[2 * gi + 1][0], r);
@@ -657,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
         for (int b = 1; b < 4; ++b) { accr[b][0] = z; accr[b][1] = z; }
       }
       const RowD db = d_bits(L), d_hid = mk_hid();
-      gemm_t<4, 4, 8>(accr, X, r, Wf, smem, [&](int) {  // the mid hidden rows and bits
+      gemm_t<4, 4, 8, GI_ACC>(accr, X, r, Wf, smem, [&](int) {  // the mid hidden rows and bits
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           st16(d_hid, vrow[0] * 256 + 16 * g, kk * 64, X[kk][0], r);
@@ -718,8 +728,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
           ft[kk][1] = ld16(d_enc, vrow[1] * 256 + 16 * g, kk * 64);
         }
         f32x4 eacc[8][2];
-        zero_acc16<8>(eacc);
-        gemm_t<8, 8, 8>(eacc, X, r, Wf, smem, NoHook());
+        gemm_t<8, 8, 8, GI_ZERO>(eacc, X, r, Wf, smem, NoHook());
         fold_enc<true>(eacc, ft, fq, g, part, raw);
       };
 #pragma unroll 1
@@ -728,8 +737,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
         const RowD db = d_bits(l - 1);
         const u32x2t b0 = ld8(db, vrow[0] * 32 + 8 * g, 0), b1 = ld8(db, vrow[1] * 32 + 8 * g, 0);
         f32x4 acc[16][2];
-        zero_acc16<16>(acc);
-        gemm_t<16, 8, 8>(acc, X, r, Wf, smem, NoHook());
+        gemm_t<16, 8, 8, GI_ZERO>(acc, X, r, Wf, smem, NoHook());
         const unsigned bm[2][2] = {{b0.x, b0.y}, {b1.x, b1.y}};
         acc_to_x16_masked<16, 8, 8>(acc, X, bm, one2);
       }
@@ -899,16 +907,14 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
       const u32x2t b0 = ld8(db, vrow[0] * 32 + 8 * g, 0), b1 = ld8(db, vrow[1] * 32 + 8 * g, 0);
       bf16x8 XR[2][2] = {{X0[0], X0[1]}, {zero8, zero8}};
       f32x4 acc[8][2];
-      zero_acc16<8>(acc);
-      gemm_t<8, 2, 2>(acc, XR, r, Wf, smem, NoHook());
+      gemm_t<8, 2, 2, GI_ZERO>(acc, XR, r, Wf, smem, NoHook());
       const unsigned bm[2][2] = {{b0.x, 0u}, {b1.x, 0u}};
       acc_to_x16_masked<8, 4, 8>(acc, X, bm, one2);  // X[0..3] = d a_mid
     }
     // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid (4 groups; the d a_mid rows leave here) -----------------
     {
       f32x4 acc[16][2];
-      zero_acc16<16>(acc);
-      gemm_t<16, 4, 8>(acc, X, r, Wf, smem, [&](int gi) {
+      gemm_t<16, 4, 8, GI_ZERO>(acc, X, r, Wf, smem, [&](int gi) {
         st16(d_damid, vrow[0] * 256 + 16 * g, gi * 64, X[gi][0], r);
         st16(d_damid, vrow[1] * 256 + 16 * g, gi * 64, X[gi][1], r);
       });
@@ -923,8 +929,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
       for (int kk = 0; kk < 8; ++kk) { X9[kk][0] = X[kk][0]; X9[kk][1] = X[kk][1]; }
       X9[8][0] = XH[0]; X9[8][1] = XH[1];
       f32x4 acc[16][2];
-      zero_acc16<16>(acc);
-      gemm_t<16, 9, 9>(acc, X9, r, Wf, smem, [&](int gi) {
+      gemm_t<16, 9, 9, GI_ZERO>(acc, X9, r, Wf, smem, [&](int gi) {
         if (gi < 8) {
           st16(d_dbott, vrow[0] * 512 + 16 * g, gi * 64, X9[gi][0], r);
           st16(d_dbott, vrow[1] * 512 + 16 * g, gi * 64, X9[gi][1], r);
@@ -946,17 +951,16 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
         ft[kk][1] = ld16(d_enc, vrow[1] * 256 + 16 * g, kk * 64);
       }
       f32x4 eacc[8][2];
-      zero_acc16<8>(eacc);
       if (l_rows >= 0) {
         const RowD dd = d_dy(l_rows);
-        gemm_t<8, 8, 8>(eacc, X, r, Wf, smem, [&](int gi) {
+        gemm_t<8, 8, 8, GI_ZERO>(eacc, X, r, Wf, smem, [&](int gi) {
           st16(dd, vrow[0] * 512 + 16 * g, (2 * gi) * 64, X[2 * gi][0], r);
           st16(dd, vrow[1] * 512 + 16 * g, (2 * gi) * 64, X[2 * gi][1], r);
           st16(dd, vrow[0] * 512 + 16 * g, (2 * gi + 1) * 64, X[2 * gi + 1][0], r);
           st16(dd, vrow[1] * 512 + 16 * g, (2 * gi + 1) * 64, X[2 * gi + 1][1], r);
         });
       } else {
-        gemm_t<8, 8, 8>(eacc, X, r, Wf, smem, NoHook());
+        gemm_t<8, 8, 8, GI_ZERO>(eacc, X, r, Wf, smem, NoHook());
       }
       fold_enc<false>(eacc, ft, fq, g, part, rawu);
     };
@@ -967,8 +971,7 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
       const u32x2t b0 = ld8(db, vrow[0] * 32 + 8 * g, 0), b1 = ld8(db, vrow[1] * 32 + 8 * g, 0);
       const RowD dd = d_dy(l);
       f32x4 acc[16][2];
-      zero_acc16<16>(acc);
-      gemm_t<16, 8, 8>(acc, X, r, Wf, smem, [&](int gi) {  // reads (and keeps) dy[l]
+      gemm_t<16, 8, 8, GI_ZERO>(acc, X, r, Wf, smem, [&](int gi) {  // reads (and keeps) dy[l]
         st16(dd, vrow[0] * 512 + 16 * g, gi * 64, X[gi][0], r);
         st16(dd, vrow[1] * 512 + 16 * g, gi * 64, X[gi][1], r);
       });
