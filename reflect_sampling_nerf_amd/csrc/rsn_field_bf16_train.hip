@@ -83,6 +83,7 @@ struct RingT {
   int e0, j0, e1, j1;  // the walk: group e_i - 1 is followed by group j_i (two jumps describe every program below)
   unsigned rd_base, rd_cur, rd_next;
   int next_slot;
+  int since;           // vector-memory operations issued since the last batch of asynchronous loads (ald8 / ald16; wait_loads)
   int c0;              // counted vector-memory operations (row stores) issued since the last group boundary ...
   int cp[LEAD - 2];    // ... and in the LEAD - 2 intervals before it (cp[0] the newest)
 };
@@ -93,6 +94,7 @@ __device__ __forceinline__ void ringt_issue(RING& r) {
   const unsigned d = __builtin_amdgcn_readfirstlane(r.lds_dst + (unsigned)r.issue_slot * RING_GROUP_BYTES);
 #pragma unroll
   for (int i = 0; i < RT_PPW; ++i) glds16(g + i * 1024, r.lane16, d + i * 1024);
+  r.since += RT_PPW;
   int n = r.issue_grp + 1;
   n = (n == r.e0) ? r.j0 : ((n == r.e1) ? r.j1 : n);
   r.issue_grp = n;
@@ -176,13 +178,6 @@ struct NoHook {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
-template <int NBO>
-__device__ __forceinline__ void zero_acc16(f32x4 (&acc)[NBO][2]) {
-  const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int b = 0; b < NBO; ++b) { acc[b][0] = z; acc[b][1] = z; }
-}
-
 // ------------------------------------------------------------------------------------------------ saved rows
 // A row-major buffer [N, row_bytes]: descriptor over the VALID rows of this wave's 32-point tile (rows past the end fall outside
 // the range and the hardware drops their stores / returns 0 for their loads); the lane addresses (row 16 p + m, 16 g bytes in).
@@ -202,6 +197,7 @@ __device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, v), d.r, voff, soff, RT_STORE_AUX);
 #ifndef RSN_RT_UNCOUNTED
   r.c0 += 1;
+  r.since += 1;
 #endif
 #endif
 }
@@ -212,22 +208,54 @@ __device__ __forceinline__ void st8(const RowD& d, unsigned voff, unsigned soff,
   __builtin_amdgcn_raw_buffer_store_b64(v, d.r, voff, soff, 0);
 #ifndef RSN_RT_UNCOUNTED
   r.c0 += 1;
+  r.since += 1;
 #endif
 #endif
 }
-__device__ __forceinline__ bf16x8 ld16(const RowD& d, unsigned voff, unsigned soff) {  // glc: written earlier by this kernel
-#ifdef RSN_RT_NO_LOADS
-  return bf16x8{};
-#else
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(d.r, voff, soff, 1));
-#endif
+// Loads of what this kernel (or the forward before it) saved -- ReLU bits, encoded features -- issued a whole GEMM ahead of their
+// use as ASYNCHRONOUS inline-asm loads: hipcc knows nothing of the LDS-DMA in flight and guards a builtin load's first use with
+// vmcnt(0), which drains the ring's whole lead at every layer of a sweep.  Here the consumer waits with the ring's own
+// arithmetic: `since` counts the vector-memory operations issued behind the batch (DMA pairs, counted stores), and
+// "at most that many outstanding" = the batch has landed (vmcnt retires in order; uncounted operations only wait longer).
+struct AsyncD {
+  u32x4t rs;  // buffer descriptor (V#), built by hand so that it can be an inline-asm operand
+};
+__device__ __forceinline__ AsyncD asyncd(const void* base, long long byte_off, int rows, int row_bytes) {
+  const unsigned long long a = (unsigned long long)(size_t)base + (base ? (unsigned long long)byte_off : 0ull);
+  AsyncD d;
+  d.rs = u32x4t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffull)),
+                (unsigned)__builtin_amdgcn_readfirstlane(base != nullptr ? rows * row_bytes : 0), 0x00020000u};
+  return d;
 }
-__device__ __forceinline__ u32x2t ld8(const RowD& d, unsigned voff, unsigned soff) {
+__device__ __forceinline__ u32x2t ald8(const AsyncD& d, unsigned voff) {
 #ifdef RSN_RT_NO_LOADS
   return u32x2t{0xffffffffu, 0xffffffffu};
 #else
-  return __builtin_amdgcn_raw_buffer_load_b64(d.r, voff, soff, 1);
+  u32x2t v;
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen sc0" : "=v"(v) : "v"(voff), "s"(d.rs) : "memory");
+  return v;
 #endif
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 ald16(const AsyncD& d, unsigned voff) {
+#ifdef RSN_RT_NO_LOADS
+  return bf16x8{};
+#else
+  u32x4t v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 sc0" : "=v"(v) : "v"(voff), "s"(d.rs), "n"(OFF) : "memory");
+  return __builtin_bit_cast(bf16x8, v);
+#endif
+}
+// the batch issued before `r.since` was reset has landed behind this
+template <class RING>
+__device__ __forceinline__ void wait_loads(RING& r) {
+  wait_vm(r.since);
+}
+__device__ __forceinline__ void tie(u32x2t& a, u32x2t& b) { asm volatile("" : "+v"(a), "+v"(b)::"memory"); }
+__device__ __forceinline__ void tie(bf16x8 (&ft)[4][2]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(ft[kk][0]), "+v"(ft[kk][1])::"memory");
 }
 
 // ------------------------------------------------------------------------------------------------ ReLU bits on packed bf16
@@ -356,6 +384,7 @@ __device__ __forceinline__ void ring_start(RING& r, const float* pk, const RsnPa
   r.rd_next = r.rd_base + (unsigned)r.next_slot * RING_GROUP_BYTES;
   r.rd_cur = r.rd_next;
   r.c0 = 0;
+  r.since = 0;
 #pragma unroll
   for (int i = 0; i < LEAD - 2; ++i) r.cp[i] = 0;
   __syncthreads();  // nothing in flight yet (also publishes the LDS tables)
@@ -720,24 +749,29 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_train_kernel(const Fiel
       }
       float part[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, raw[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
       auto enc_part = [&]() {  // eacc = (encoded-input part)^T x gradient, folded at once with the lane's saved features
-        const RowD d_enc = mk_enc();
+        const AsyncD d_enc = asyncd(a.saved.enc, (long long)p0 * 256, rows, 256);
         bf16x8 ft[4][2];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          ft[kk][0] = ld16(d_enc, vrow[0] * 256 + 16 * g, kk * 64);
-          ft[kk][1] = ld16(d_enc, vrow[1] * 256 + 16 * g, kk * 64);
-        }
+        ft[0][0] = ald16<0>(d_enc, vrow[0] * 256 + 16 * g); ft[0][1] = ald16<0>(d_enc, vrow[1] * 256 + 16 * g);
+        ft[1][0] = ald16<64>(d_enc, vrow[0] * 256 + 16 * g); ft[1][1] = ald16<64>(d_enc, vrow[1] * 256 + 16 * g);
+        ft[2][0] = ald16<128>(d_enc, vrow[0] * 256 + 16 * g); ft[2][1] = ald16<128>(d_enc, vrow[1] * 256 + 16 * g);
+        ft[3][0] = ald16<192>(d_enc, vrow[0] * 256 + 16 * g); ft[3][1] = ald16<192>(d_enc, vrow[1] * 256 + 16 * g);
+        r.since = 0;
         f32x4 eacc[8][2];
         gemm_t<8, 8, 8, GI_ZERO>(eacc, X, r, Wf, smem, NoHook());
+        wait_loads(r);
+        tie(ft);
         fold_enc<true>(eacc, ft, fq, g, part, raw);
       };
 #pragma unroll 1
       for (int l = L - 1; l >= 1; --l) {
         if (l == P.skip_layer) enc_part();
-        const RowD db = d_bits(l - 1);
-        const u32x2t b0 = ld8(db, vrow[0] * 32 + 8 * g, 0), b1 = ld8(db, vrow[1] * 32 + 8 * g, 0);
+        const AsyncD db = asyncd(a.saved.relu_bits, ((long long)(l - 1) * n_max + p0) * 32, rows, 32);
+        u32x2t b0 = ald8(db, vrow[0] * 32 + 8 * g), b1 = ald8(db, vrow[1] * 32 + 8 * g);
+        r.since = 0;
         f32x4 acc[16][2];
         gemm_t<16, 8, 8, GI_ZERO>(acc, X, r, Wf, smem, NoHook());
+        wait_loads(r);
+        tie(b0, b1);
         const unsigned bm[2][2] = {{b0.x, b0.y}, {b1.x, b1.y}};
         acc_to_x16_masked<16, 8, 8>(acc, X, bm, one2);
       }
@@ -809,7 +843,6 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
     auto d_dy = [&](int l) { return rowd(a.gout.dy, ((long long)l * n_max + p0) * 512, rows, 512); };
     const RowD d_damid = rowd(a.gout.da_mid, (long long)p0 * 256, rows, 256);
     const RowD d_dbott = rowd(a.gout.d_bott, (long long)p0 * 512, rows, 512);
-    const RowD d_enc = rowd(a.saved.enc, (long long)p0 * 256, rows, 256);
 
     // ---------------- per-sample epilogue gradients (reference autograd restated: see rsn_field_bwd.hip) -----------------
     bf16x8 X[8][2];
@@ -903,11 +936,14 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
 
     // ---------------- stage 1: d hidden = W_rgb^T dz (one group), masked by the mid hidden layer's ReLU -----------------
     {
-      const RowD db = d_bits(L);
-      const u32x2t b0 = ld8(db, vrow[0] * 32 + 8 * g, 0), b1 = ld8(db, vrow[1] * 32 + 8 * g, 0);
+      const AsyncD db = asyncd(a.saved.relu_bits, ((long long)L * n_max + p0) * 32, rows, 32);
+      u32x2t b0 = ald8(db, vrow[0] * 32 + 8 * g), b1 = ald8(db, vrow[1] * 32 + 8 * g);
+      r.since = 0;
       bf16x8 XR[2][2] = {{X0[0], X0[1]}, {zero8, zero8}};
       f32x4 acc[8][2];
       gemm_t<8, 2, 2, GI_ZERO>(acc, XR, r, Wf, smem, NoHook());
+      wait_loads(r);
+      tie(b0, b1);
       const unsigned bm[2][2] = {{b0.x, 0u}, {b1.x, 0u}};
       acc_to_x16_masked<8, 4, 8>(acc, X, bm, one2);  // X[0..3] = d a_mid
     }
@@ -922,8 +958,9 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
     }
     // ---------------- stage 3: d emb = [W_b; W_heads]^T [d b; dz_heads] (9 groups), masked by the embedding's ReLU -----------------
     {
-      const RowD db = d_bits(L - 1);
-      const u32x2t b0 = ld8(db, vrow[0] * 32 + 8 * g, 0), b1 = ld8(db, vrow[1] * 32 + 8 * g, 0);
+      const AsyncD db = asyncd(a.saved.relu_bits, ((long long)(L - 1) * n_max + p0) * 32, rows, 32);
+      u32x2t b0 = ald8(db, vrow[0] * 32 + 8 * g), b1 = ald8(db, vrow[1] * 32 + 8 * g);
+      r.since = 0;
       bf16x8 X9[9][2];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) { X9[kk][0] = X[kk][0]; X9[kk][1] = X[kk][1]; }
@@ -935,6 +972,8 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
           st16(d_dbott, vrow[1] * 512 + 16 * g, gi * 64, X9[gi][1], r);
         }
       });
+      wait_loads(r);
+      tie(b0, b1);
       const unsigned bm[2][2] = {{b0.x, b0.y}, {b1.x, b1.y}};
       acc_to_x16_masked<16, 8, 8>(acc, X, bm, one2);  // X = dy[L-1]
     }
@@ -944,12 +983,13 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
 #pragma unroll
     for (int t = 0; t < 4; ++t) fq[t] = P.freqs[4 * g + t];
     auto enc_part = [&](int l_rows) {  // (encoded-input part)^T x dy[l_rows], folded into the variance gradient; dy[l_rows] may leave here
+      const AsyncD d_enc = asyncd(a.saved.enc, (long long)p0 * 256, rows, 256);
       bf16x8 ft[4][2];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        ft[kk][0] = ld16(d_enc, vrow[0] * 256 + 16 * g, kk * 64);
-        ft[kk][1] = ld16(d_enc, vrow[1] * 256 + 16 * g, kk * 64);
-      }
+      ft[0][0] = ald16<0>(d_enc, vrow[0] * 256 + 16 * g); ft[0][1] = ald16<0>(d_enc, vrow[1] * 256 + 16 * g);
+      ft[1][0] = ald16<64>(d_enc, vrow[0] * 256 + 16 * g); ft[1][1] = ald16<64>(d_enc, vrow[1] * 256 + 16 * g);
+      ft[2][0] = ald16<128>(d_enc, vrow[0] * 256 + 16 * g); ft[2][1] = ald16<128>(d_enc, vrow[1] * 256 + 16 * g);
+      ft[3][0] = ald16<192>(d_enc, vrow[0] * 256 + 16 * g); ft[3][1] = ald16<192>(d_enc, vrow[1] * 256 + 16 * g);
+      r.since = 0;
       f32x4 eacc[8][2];
       if (l_rows >= 0) {
         const RowD dd = d_dy(l_rows);
@@ -962,19 +1002,24 @@ __global__ __launch_bounds__(512, 2) void rsn_field_bf16_bwd_kernel(const BwdJob
       } else {
         gemm_t<8, 8, 8, GI_ZERO>(eacc, X, r, Wf, smem, NoHook());
       }
+      wait_loads(r);
+      tie(ft);
       fold_enc<false>(eacc, ft, fq, g, part, rawu);
     };
 #pragma unroll 1
     for (int l = L - 1; l >= 1; --l) {
       if (INPUT && l == P.skip_layer) enc_part(-1);
-      const RowD db = d_bits(l - 1);
-      const u32x2t b0 = ld8(db, vrow[0] * 32 + 8 * g, 0), b1 = ld8(db, vrow[1] * 32 + 8 * g, 0);
+      const AsyncD db = asyncd(a.saved.relu_bits, ((long long)(l - 1) * n_max + p0) * 32, rows, 32);
+      u32x2t b0 = ald8(db, vrow[0] * 32 + 8 * g), b1 = ald8(db, vrow[1] * 32 + 8 * g);
+      r.since = 0;
       const RowD dd = d_dy(l);
       f32x4 acc[16][2];
       gemm_t<16, 8, 8, GI_ZERO>(acc, X, r, Wf, smem, [&](int gi) {  // reads (and keeps) dy[l]
         st16(dd, vrow[0] * 512 + 16 * g, gi * 64, X[gi][0], r);
         st16(dd, vrow[1] * 512 + 16 * g, gi * 64, X[gi][1], r);
       });
+      wait_loads(r);
+      tie(b0, b1);
       const unsigned bm[2][2] = {{b0.x, b0.y}, {b1.x, b1.y}};
       acc_to_x16_masked<16, 8, 8>(acc, X, bm, one2);  // X = dy[l-1]
     }
