@@ -58,6 +58,11 @@ typedef struct rsn_field_desc {
   float density_bias;   /* 0.5 */
   float freqs[RSN_NUM_FREQS];
   int32_t mma_mode;     /* arithmetic of the dense GEMMs in the eval field kernel (rsn_mma_mode) */
+  int32_t param_width;  /* base_mlp_layer_width of the PARAMETER tensors when it is not one of the widths the kernels run at:
+                         * any 1 <= param_width <= width; 0 = width.  The kernels run at `width` (the next of 64 / 128 / 256)
+                         * with zero-padded units: rsn_pack_weights gives units param_width .. width - 1 zero weights and
+                         * biases, their activations and gradients are exact zeros, every wide buffer ([N, W] rows) has
+                         * `width` columns of which the first param_width are live (ABI 15) */
 } rsn_field_desc;
 
 /* How the field kernel multiplies fp32 operands on the matrix cores:

@@ -326,6 +326,12 @@ def main():
     # the no-mask early-out (model.py:259-260) at a width the kernels accept
     run_case("eval_l6_w64_nomask", R=16, samples=(8, 8, 8, 8), layers=6, width=64, training=False, seed=4,
              density_bias_shift=-12.0)
+    # ---- widths that are NOT one of the kernels' 64 / 128 / 256: the HIP path runs them zero-padded (rsn_field_desc.param_width)
+    run_train_step_case("trainstep_l6_w48", R=24, samples=(16, 16, 8, 8), layers=6, width=48, seed=12, density_bias_shift=2.0)
+    run_case("eval_l8_w200", R=16, samples=(16, 16, 8, 8), layers=8, width=200, training=False, seed=13,
+             density_bias_shift=2.0, param_file="params_l8_w200_seed13")
+    run_train_step_case("trainstep_l8_w200", R=12, samples=(16, 16, 8, 8), layers=8, width=200, seed=13,
+                        density_bias_shift=2.0, param_file="params_l8_w200_seed13", ray_seed=23)
     run_units()
 
 

@@ -29,6 +29,7 @@ class FieldDesc(C.Structure):
         ("density_bias", C.c_float),
         ("freqs", C.c_float * RSN_NUM_FREQS),
         ("mma_mode", C.c_int32),
+        ("param_width", C.c_int32),
     ]
 
 

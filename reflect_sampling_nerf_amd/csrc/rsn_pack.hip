@@ -69,6 +69,8 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   RSN_REQUIRE(d->width == 64 || d->width == 128 || d->width == 256, RSN_ERR_UNSUPPORTED,
               "width=%d unsupported (64, 128 or 256)", d->width);
   RSN_REQUIRE(d->mid_width == 128, RSN_ERR_UNSUPPORTED, "mid_width=%d unsupported (128)", d->mid_width);
+  RSN_REQUIRE(d->param_width >= 0 && d->param_width <= d->width, RSN_ERR_INVALID_ARGUMENT,
+              "param_width=%d must be 0 (= width) or 1..width=%d", d->param_width, d->width);
   RSN_REQUIRE(d->mma_mode >= RSN_MMA_F32 && d->mma_mode <= RSN_MMA_BF16, RSN_ERR_INVALID_ARGUMENT, "mma_mode=%d",
               d->mma_mode);
   RSN_REQUIRE(d->skip_layer == -1 || (d->skip_layer >= 1 && d->skip_layer <= d->num_layers - 2),
@@ -504,7 +506,9 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   RSN_REQUIRE(packed_bytes >= L.total * sizeof(float), RSN_ERR_WORKSPACE,
               "packed buffer too small: %zu < %zu bytes", packed_bytes, L.total * sizeof(float));
   hipStream_t st = (hipStream_t)stream;
-  const int W = d->width, NB = L.nb, NBM = L.nbm;
+  // WP: the width the kernels run at (64 / 128 / 256); W: the width of the PARAMETER tensors (rsn_field_desc.param_width): units
+  // W .. WP - 1 get zero weights and zero biases (their activations and gradients are exact zeros)
+  const int WP = d->width, W = (d->param_width > 0 ? d->param_width : d->width), NB = L.nb, NBM = L.nbm;
   PackJob j;
 
   for (int l = 0; l < d->num_layers; ++l) {
@@ -529,7 +533,7 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       }
     }
     clear_job(j);
-    j.is_bias = 1; j.src[0] = p->trunk_b[l]; j.dst = packed + L.b[l]; j.n_rows = W;
+    j.is_bias = 1; j.src[0] = p->trunk_b[l]; j.dst = packed + L.b[l]; j.n_rows = WP;
     rows_natural(j, W);
     if ((rc = launch(j, st)) != RSN_OK) return rc;
   }
@@ -555,13 +559,13 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   j.src[4] = p->roughness_w; j.src[5] = p->tint_w;
   for (int i = 0; i < PACK_MAX_SRC; ++i) j.ld[i] = W;
   j.dst = packed + L.w_bh; j.n_it = NB * 4; j.nbo = NB + 1;
-  rows_natural(j, W); heads_rows(j, W); cols_natural(j, W, 0);
+  rows_natural(j, W); heads_rows(j, WP); cols_natural(j, W, 0);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
   clear_job(j);
-  j.is_bias = 1; j.n_rows = W + 32; j.dst = packed + L.b_bh;
+  j.is_bias = 1; j.n_rows = WP + 32; j.dst = packed + L.b_bh;
   j.src[0] = p->bottleneck_b; j.src[1] = p->density_b; j.src[2] = p->normals_b; j.src[3] = p->diff_b;
   j.src[4] = p->roughness_b; j.src[5] = p->tint_b;
-  rows_natural(j, W); heads_rows(j, W);
+  rows_natural(j, W); heads_rows(j, WP);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
 
   // mlp_mid: input cat([SH(34), bottleneck(W)])
@@ -643,7 +647,7 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
   for (int c = 0; c < 3; ++c) j.col[4 + c] = (int16_t)c;
   if ((rc = launch(j, st)) != RSN_OK) return rc;
   clear_job(j);
-  j.is_bias = 1; j.n_rows = W; j.src[0] = p->density_w; j.dst = packed + L.v_density;
+  j.is_bias = 1; j.n_rows = WP; j.src[0] = p->density_w; j.dst = packed + L.v_density;
   rows_natural(j, W);
   if ((rc = launch(j, st)) != RSN_OK) return rc;
 
@@ -656,11 +660,11 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     // the next layer is the natural one (slot (kk, g, e) <- feature 32 kk + 8 g + e, lane-local hand-off as before), and a
     // training kernel stores a lane's share of an activation row as ONE 16-byte piece per K-step (the four lanes of a
     // point cover 64 contiguous bytes) instead of two 8-byte pieces 32 bytes apart.
-    auto rows_perm16 = [&](PackJob& jj, int n_rows, int src = 0) {
+    auto rows_perm16 = [&](PackJob& jj, int n_rows, int n_valid) {  // features >= n_valid (zero-padded units): zero rows
       for (int n = 0; n < n_rows; ++n) {
-        const int b = n >> 4, i = n & 15;
-        jj.row_src[n] = (int16_t)src;
-        jj.row_idx[n] = (int16_t)(32 * (b >> 1) + 8 * (i >> 2) + 4 * (b & 1) + (i & 3));
+        const int b = n >> 4, i = n & 15, feat = 32 * (b >> 1) + 8 * (i >> 2) + 4 * (b & 1) + (i & 3);
+        jj.row_src[n] = (int16_t)(feat < n_valid ? 0 : -1);
+        jj.row_idx[n] = (int16_t)(feat < n_valid ? feat : 0);
       }
     };
     auto cols_x16 = [&](PackJob& jj, int K, int offset) { cols_natural(jj, K, offset); };
@@ -689,16 +693,16 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       return launch(jj, st);
     };
     clear_job(j);
-    j.src[0] = p->trunk_w[0]; j.ld[0] = RSN_ENC_DIM; rows_perm16(j, W); cols_enc16(j);
+    j.src[0] = p->trunk_w[0]; j.ld[0] = RSN_ENC_DIM; rows_perm16(j, WP, W); cols_enc16(j);
     if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
     for (int l = 1; l < d->num_layers; ++l) {
       const int in_f = (l == d->skip_layer) ? RSN_ENC_DIM + W : W;
       clear_job(j);
-      j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_perm16(j, W); cols_x16(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0);
+      j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_perm16(j, WP, W); cols_x16(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0);
       if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
       if (l == d->skip_layer) {
         clear_job(j);
-        j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_perm16(j, W); cols_enc16(j);
+        j.src[0] = p->trunk_w[l]; j.ld[0] = in_f; rows_perm16(j, WP, W); cols_enc16(j);
         if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
       }
     }
@@ -708,13 +712,13 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     heads_rows(j, 0); cols_x16(j, W, 0);
     if ((rc = qpiece(j, 8, 2)) != RSN_OK) return rc;
     clear_job(j);
-    j.src[0] = p->bottleneck_w; j.ld[0] = W; rows_perm16(j, W); cols_x16(j, W, 0);
+    j.src[0] = p->bottleneck_w; j.ld[0] = W; rows_perm16(j, WP, W); cols_x16(j, W, 0);
     if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
     clear_job(j);
-    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_perm16(j, d->mid_width); cols_sh16(j);
+    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_perm16(j, d->mid_width, d->mid_width); cols_sh16(j);
     if ((rc = qpiece(j, 2, 8)) != RSN_OK) return rc;
     clear_job(j);
-    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_perm16(j, d->mid_width); cols_x16(j, W, RSN_SH_DIM);
+    j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rows_perm16(j, d->mid_width, d->mid_width); cols_x16(j, W, RSN_SH_DIM);
     if ((rc = qpiece(j, 8, 8)) != RSN_OK) return rc;
     clear_job(j);  // RGB head: rows 4..6 of the first of four 16-row blocks (three of them zero: whole-group padding)
     j.src[0] = p->rgb_w; j.ld[0] = d->mid_width;
@@ -725,11 +729,11 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
                 frag, L.q_groups);
     // ---- transposed pieces (training sweeps): packed ROW 16 b + 4 g + r <- input feature r16_feature (source COLUMN), packed
     //      K natural <- output feature (source ROW); transpose = 1 (see above: row_idx selects the source column)
-    auto rowsT_perm16 = [&](PackJob& jj, int n_rows, int col_offset) {
+    auto rowsT_perm16 = [&](PackJob& jj, int n_rows, int n_valid, int col_offset) {
       for (int n = 0; n < n_rows; ++n) {
-        const int b = n >> 4, i = n & 15;
-        jj.row_src[n] = 0;
-        jj.row_idx[n] = (int16_t)(col_offset + 32 * (b >> 1) + 8 * (i >> 2) + 4 * (b & 1) + (i & 3));
+        const int b = n >> 4, i = n & 15, feat = 32 * (b >> 1) + 8 * (i >> 2) + 4 * (b & 1) + (i & 3);
+        jj.row_src[n] = (int16_t)(feat < n_valid ? 0 : -1);
+        jj.row_idx[n] = (int16_t)(feat < n_valid ? col_offset + feat : 0);
       }
     };
     // encoded-input slots as packed rows: row 16 b + 4 g + r = slot (kk = b / 2, g, e = 4 (b % 2) + r) of cols_enc16
@@ -745,14 +749,14 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       }
     };
     clear_job(j);  // (RGB head)^T: rows = 128 hidden features; K-step 0 slot (g = 1, e = 0..2) = k 8..10 <- rgb row 0..2; K-step 1 zero
-    j.transpose = 1; j.src[0] = p->rgb_w; j.ld[0] = d->mid_width; rowsT_perm16(j, d->mid_width, 0);
+    j.transpose = 1; j.src[0] = p->rgb_w; j.ld[0] = d->mid_width; rowsT_perm16(j, d->mid_width, d->mid_width, 0);
     for (int c = 0; c < 3; ++c) j.col[8 + c] = (int16_t)c;
     if ((rc = qpiece(j, 2, 8)) != RSN_OK) return rc;
     clear_job(j);  // (mlp_mid x part)^T: rows = W bottleneck features (source columns 34..), K = 128 hidden rows
-    j.transpose = 1; j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rowsT_perm16(j, W, RSN_SH_DIM); cols_natural(j, d->mid_width, 0);
+    j.transpose = 1; j.src[0] = p->mid_w; j.ld[0] = RSN_SH_DIM + W; rowsT_perm16(j, WP, W, RSN_SH_DIM); cols_natural(j, d->mid_width, 0);
     if ((rc = qpiece(j, 4, 16)) != RSN_OK) return rc;
     clear_job(j);  // [bottleneck]^T: rows = W embedding features, K = W bottleneck rows ...
-    j.transpose = 1; j.src[0] = p->bottleneck_w; j.ld[0] = W; rowsT_perm16(j, W, 0); cols_natural(j, W, 0);
+    j.transpose = 1; j.src[0] = p->bottleneck_w; j.ld[0] = W; rowsT_perm16(j, WP, W, 0); cols_natural(j, W, 0);
     if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
     {  // ... + [heads]^T as a ninth K-step: slot (g, e < 4) = k 8 g + e <- heads row 4 g + e (0 density, 1-3 normals, 4-6 diff, 8 roughness, 12-14 tint)
       const float* hw[5] = {p->density_w, p->normals_w, p->diff_w, p->roughness_w, p->tint_w};
@@ -761,7 +765,7 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       clear_job(j);
       j.transpose = 3;
       for (int t = 0; t < 5; ++t) { j.src[t] = hw[t]; j.ld[t] = W; }
-      rowsT_perm16(j, W, 0);
+      rowsT_perm16(j, WP, W, 0);
       for (int t = 0; t < 5; ++t)
         for (int c = 0; c < hrows[t]; ++c) {
           const int hr = hbase[t] + c;  // heads row 4 g + e
@@ -779,7 +783,7 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       }
       clear_job(j);
       j.transpose = 1; j.src[0] = p->trunk_w[l]; j.ld[0] = in_f;
-      rowsT_perm16(j, W, l == d->skip_layer ? RSN_ENC_DIM : 0); cols_natural(j, W, 0);
+      rowsT_perm16(j, WP, W, l == d->skip_layer ? RSN_ENC_DIM : 0); cols_natural(j, W, 0);
       if ((rc = qpiece(j, 8, 16)) != RSN_OK) return rc;
     }
     clear_job(j);

@@ -124,8 +124,20 @@ class ReflectSamplingNeRFNerfField(Field):
 
     # ------------------------------------------------------------------ C-ABI plumbing
     @property
-    def width(self) -> int:
+    def param_width(self) -> int:
+        """base_mlp_layer_width: the width of the parameter tensors (reference field.py:41)."""
         return self.mlp_base.layer_width
+
+    @property
+    def width(self) -> int:
+        """The width the kernels run at: the next of 64 / 128 / 256 at or above base_mlp_layer_width.  Units beyond
+        param_width are zero-padded by rsn_pack_weights (zero weights, zero biases: their activations and gradients are exact
+        zeros); every wide buffer of the C ABI ([N, W] rows) has this many columns."""
+        pw = self.mlp_base.layer_width
+        for w in (64, 128, 256):
+            if pw <= w:
+                return w
+        raise NotImplementedError(f"base_mlp_layer_width={pw}: the fused kernels hold at most 256 units per layer")
 
     def field_desc(self) -> FieldDesc:
         if self._desc is None:
@@ -134,6 +146,7 @@ class ReflectSamplingNeRFNerfField(Field):
             d = FieldDesc()
             d.num_layers = L
             d.width = self.width
+            d.param_width = self.param_width
             d.skip_layer = live[0] if live else -1
             d.mid_width = self.mlp_mid.layer_width
             d.density_bias = float(self.density_bias)
@@ -368,6 +381,7 @@ class ReflectSamplingNeRFNerfField(Field):
         if cov is not None:
             cd = ops._f32c(torch.diagonal(cov, dim1=-2, dim2=-1).reshape(-1, 3))
         lv = self.evaluate_gaussians(m, cd, None, want_embedding=True)
+        lv["embedding"] = lv["embedding"][:, : self.param_width]  # the kernels' padded units (exact zeros) are not part of the API
         self._last_level = {k: v.reshape(*shp, -1) for k, v in lv.items()}
         return self._last_level["sigma"], self._last_level["embedding"]
 
@@ -416,7 +430,10 @@ class ReflectSamplingNeRFNerfField(Field):
                mid_only: bool = False) -> Dict[str, Tensor]:
         lib = _abi.load_library()
         shp = embedding.shape[:-1]
-        e = ops._f32c(embedding.reshape(-1, self.width))
+        e = embedding.reshape(-1, self.param_width)
+        if self.param_width != self.width:  # zero-padded units of the kernels' width
+            e = torch.nn.functional.pad(e, (0, self.width - self.param_width))
+        e = ops._f32c(e)
         N, dev = e.shape[0], e.device
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         lv = {"color": f(N, 3)}

@@ -115,7 +115,7 @@ class _GradAcc:
     def __init__(self, field):
         self.field = field
         dev = next(field.parameters()).device
-        W = field.width
+        W = field.param_width  # the heads block has the parameters' width (the kernels' zero-padded units have no gradient)
         # one flat zero-filled buffer (one fill kernel per step), viewed per parameter + the two heads blocks
         named = [(n, p) for n, p in field.named_parameters() if "field_output_low" not in n]
         sizes = [p.numel() for _, p in named] + [16 * W, 16]
@@ -227,7 +227,9 @@ def _weight_grads(field, levels, acc: _GradAcc):
     reads the count itself and takes the first count * rows-per-count rows."""
     global _WGRAD_MODE
     _WGRAD_MODE = int(field.mma_mode)  # bf16x6: split operands (fp32-equivalent); bf16: rounded operands (reduced precision)
-    L, W = field.mlp_base.num_layers, field.width
+    # W: the PARAMETER width (n_out / k_in of the reductions); the operand rows are [N, field.width] (leading dimension = the
+    # kernels' padded width, taken from the tensors' strides)
+    L, W = field.mlp_base.num_layers, field.param_width
     skip = field.field_desc().skip_layer
     enc_map, sh_map = field._enc_col_map, field._sh_col_map
     g = acc.g

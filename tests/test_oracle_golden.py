@@ -13,9 +13,11 @@ CASES = ["eval_l8_w32", "train_l8_w32", "eval_l4_w32", "eval_l6_w32_nomask", "ev
          "eval_l8_w256", "eval_l4_w128", "eval_l6_w64_nomask",
          # TRAINED weights: the reference trained by oracle/make_golden_trained.py (its own get_outputs / get_loss_dict /
          # RAdam on the procedural scene) until it left the initialisation regime, then recorded
-         "eval_trained_l8_w64", "eval_trained_l8_w256"]
+         "eval_trained_l8_w64", "eval_trained_l8_w256",
+         # a width that is not one of the kernels' 64 / 128 / 256 (the HIP path runs it zero-padded)
+         "eval_l8_w200"]
 TRAIN_STEP_CASES = ["trainstep_l8_w64", "trainstep_l8_w256", "trainstep_l4_w128",
-                    "trainstep_trained_l8_w64", "trainstep_trained_l8_w256"]
+                    "trainstep_trained_l8_w64", "trainstep_trained_l8_w256", "trainstep_l6_w48", "trainstep_l8_w200"]
 
 
 @pytest.mark.parametrize("name", CASES)
