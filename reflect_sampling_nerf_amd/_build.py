@@ -17,7 +17,7 @@ REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(REPO, "build", "obj")
 LIB_PATH = os.path.join(PKG_DIR, "librsn_hip.so")
-SOURCES = ["rsn_pack.hip", "rsn_field.hip", "rsn_field_split.hip", "rsn_field_bf16.hip", "rsn_field_bf16_train.hip", "rsn_field_bwd.hip", "rsn_wgrad.hip", "rsn_render.hip", "rsn_train_ops.hip"]
+SOURCES = ["rsn_pack.hip", "rsn_field.hip", "rsn_field_split.hip", "rsn_field_bf16.hip", "rsn_field_bf16_train.hip", "rsn_field_x6_train.hip", "rsn_field_bwd.hip", "rsn_wgrad.hip", "rsn_render.hip", "rsn_train_ops.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17"]
 # Per-file flags on top of FLAGS.  -amdgpu-mfma-vgpr-form: MFMA accumulators in architected VGPRs instead of AGPRs.  The
 # field kernels' layer epilogues read every accumulator (ReLU, mask bits, LDS hand-off, saved rows) and re-load it with
@@ -26,7 +26,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # step's forward / backward sweeps run 1.4 % / 1.5 % faster (profiles/r03_vgpr_form.txt).  NOT for rsn_wgrad.hip: its
 # 256-accumulator kernels need the AGPR half of the file for them (605 spills in VGPR form).
 _MFMA_VGPR = ("-mllvm", "-amdgpu-mfma-vgpr-form")
-SOURCE_FLAGS = {"rsn_field.hip": _MFMA_VGPR, "rsn_field_bwd.hip": _MFMA_VGPR}
+# -pragma-unroll-threshold: the split-bf16 ring GEMMs are fully unrolled loops of up to 27 groups x 16 pieces (static register indices
+# for the activations); hipcc prices them above its default 16 K budget, unrolls them late and partially, and the activation /
+# accumulator arrays then live in scratch (832 B per lane).  With the budget raised: no scratch in the backward kernels.
+_UNROLL_BUDGET = ("-mllvm", "-pragma-unroll-threshold=131072")
+SOURCE_FLAGS = {"rsn_field.hip": _MFMA_VGPR, "rsn_field_bwd.hip": _MFMA_VGPR, "rsn_field_x6_train.hip": _UNROLL_BUDGET}
 
 
 def _headers():

@@ -98,16 +98,20 @@ struct RsnPackedLayout {
   // last (layer 0)^T 4 groups.  The backward sweep walks all of it (without the two encoded-input pieces when no input
   // gradient is wanted); the analytic-normal sweep of the training forward walks [t_g_trunk, t_g_end) behind the forward stream.
   int t_g_begin, t_g_trunk, t_g_encskip, t_g_enc0, t_g_end;   // absolute group indices from q_stream; t_g_encskip = -1: no skip layer
+  // RSN_MMA_BF16X6 at width 256 (rsn_field_x6_train.hip): the same stream with every fragment as THREE 1 KiB pieces -- the lo, mid
+  // and hi bf16 parts of the fp32 weights, in that order (small products first); q_pf = 3 and every group count above is x 3
+  int q_pf;                           // 1 KiB pieces per fragment of q_stream: 1 (plain bf16) or 3 (split-bf16)
   size_t total;                       // floats
 };
 #ifndef RSN_RING_GROUP_FRAGS
 #define RSN_RING_GROUP_FRAGS 16
 #endif
 #define RSN_RING_MAX_LAYERS 10   // trunk depth the ring kernels' LDS bias table is sized for
-// the plain-bf16 TRAINING kernels on the LDS weight ring (rsn_field_bf16_train.hip) serve this shape; every other shape /
-// mode trains on rsn_field_kernel<., true, .> / rsn_field_bwd_kernel
+// the TRAINING kernels on the LDS weight ring (rsn_field_bf16_train.hip: plain bf16; rsn_field_x6_train.hip: split-bf16) serve
+// this shape; every other shape / mode trains on rsn_field_kernel<., true, .> / rsn_field_bwd_kernel
 inline bool rsn_ring_training(const rsn_field_desc* d) {
-  return d->mma_mode == RSN_MMA_BF16 && d->width == 256 && d->num_layers <= RSN_RING_MAX_LAYERS && RSN_RING_GROUP_FRAGS == 16;
+  return (d->mma_mode == RSN_MMA_BF16 || d->mma_mode == RSN_MMA_BF16X6) && d->width == 256 &&
+         d->num_layers <= RSN_RING_MAX_LAYERS && RSN_RING_GROUP_FRAGS == 16;
 }
 
 int rsn_compute_layout(const rsn_field_desc* desc, RsnPackedLayout* L);

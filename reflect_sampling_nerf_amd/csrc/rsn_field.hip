@@ -71,10 +71,11 @@ static int launch_field_jobs(const rsn_field_desc* d, FieldArgs* js, int n, void
     const long long g2 = n_tiles < 2LL * cus ? n_tiles : 2LL * cus;
     return rsn_launch_field_bf16(d->width, g2, st, one);
   }
-  if (train && rsn_ring_training(d)) {  // plain-bf16 training at width 256: the LDS-ring kernels (256-point tiles)
-    long long t256 = 0;
-    for (int k = 0; k < J.n_jobs; ++k) t256 += ((long long)J.j[k].n_rays * J.j[k].S + 255) / 256;
-    return rsn_launch_field_bf16_train(t256, st, J);
+  if (train && rsn_ring_training(d)) {  // plain / split bf16 training at width 256: the LDS-ring kernels (256- / 128-point tiles)
+    const int tp = mode == RSN_MMA_BF16X6 ? 128 : 256;
+    long long tn = 0;
+    for (int k = 0; k < J.n_jobs; ++k) tn += ((long long)J.j[k].n_rays * J.j[k].S + tp - 1) / tp;
+    return mode == RSN_MMA_BF16X6 ? rsn_launch_field_x6_train(tn, st, J) : rsn_launch_field_bf16_train(tn, st, J);
   }
   if (mode == RSN_MMA_BF16X6 || (!train && mode == RSN_MMA_BF16X3)) {  // split-bf16 instantiations: rsn_field_split.hip
     rc = rsn_launch_field_split(d->width, train, mode == RSN_MMA_BF16X6 ? 1 : 2, grid, st, J);

@@ -295,10 +295,11 @@ static int launch_bwd_jobs(const rsn_field_desc* d, BwdArgs* js, int n, void* st
   const int cached_cus = rsn_device_cus();
   const long long grid = n_tiles < (long long)cached_cus ? n_tiles : (long long)cached_cus;
   hipStream_t st = (hipStream_t)stream;
-  if (rsn_ring_training(d)) {  // plain-bf16 training at width 256: the LDS-ring kernels (256-point tiles)
-    long long t256 = 0;
-    for (int k = 0; k < J.n_jobs; ++k) t256 += ((long long)J.j[k].n_rays * J.j[k].S + 255) / 256;
-    return rsn_launch_field_bf16_bwd(t256, st, J);
+  if (rsn_ring_training(d)) {  // plain / split bf16 training at width 256: the LDS-ring kernels (256- / 128-point tiles)
+    const int tp = d->mma_mode == RSN_MMA_BF16X6 ? 128 : 256;
+    long long tn = 0;
+    for (int k = 0; k < J.n_jobs; ++k) tn += ((long long)J.j[k].n_rays * J.j[k].S + tp - 1) / tp;
+    return d->mma_mode == RSN_MMA_BF16X6 ? rsn_launch_field_x6_bwd(tn, st, J) : rsn_launch_field_bf16_bwd(tn, st, J);
   }
   const bool x6 = d->mma_mode == RSN_MMA_BF16X6;  // fp32-emulating split-bf16 sweeps (opt-in); else exact fp32
 #define RSN_LAUNCH_BWD(NBV)                                                                                  \

@@ -103,3 +103,6 @@ __device__ __forceinline__ void normalize_bwd(const float x[3], const float gy[3
 // rsn_field_bf16_train.hip: the plain-bf16 training kernels on the LDS weight ring (width 256; rsn_ring_training())
 int rsn_launch_field_bf16_train(long long n_tiles256, hipStream_t st, const FieldJobs& J);
 int rsn_launch_field_bf16_bwd(long long n_tiles256, hipStream_t st, const BwdJobs& J);
+// rsn_field_x6_train.hip: the split-bf16 (fp32-equivalent) training kernels on the LDS weight ring (width 256; 128-point tiles)
+int rsn_launch_field_x6_train(long long n_tiles128, hipStream_t st, const FieldJobs& J);
+int rsn_launch_field_x6_bwd(long long n_tiles128, hipStream_t st, const BwdJobs& J);

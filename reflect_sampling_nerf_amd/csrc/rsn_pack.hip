@@ -165,6 +165,7 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
   off += (size_t)(L->nbm * 2) * L->nb * 3 * blk;
   L->hT_rgb = off;
   off += (size_t)2 * L->nbm * 3 * blk;
+  L->q_pf = 1;
   if (d->mma_mode == RSN_MMA_BF16 && d->width == 256) {
     // enc0 7 K-steps x 8 blocks; x layers 16 x 8; enc_skip 7 x 8; heads 16 x 1; bottleneck 16 x 8; mlp_mid SH part
     // 3 (padded to 4) x 4; mlp_mid x part 16 x 4; rgb 8 x 1 -- every GEMM a whole number of 8-fragment groups
@@ -173,25 +174,29 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
     L->r_groups = (enc_ks * 8 * (d->skip_layer >= 1 ? 2 : 1) + (d->num_layers - 1) * 128 + 16 + 128 + 16 + 64 + rgb_ks) / G;
     L->r_stream = off;
     off += (size_t)L->r_groups * RSN_RING_GROUP_FRAGS * blk;
-    if (G == 16) {  // 16x32 fragments: enc 4 x 16, x 8 x 16, heads 8 x 2, bottleneck 8 x 16, mid SH 2 x 8, mid x 8 x 8, rgb 4 x 4
-      L->q_groups = (64 * (d->skip_layer >= 1 ? 2 : 1) + (d->num_layers - 1) * 128 + 16 + 128 + 16 + 64 + 16) / 16;
-      L->q_stream = off;
-      off += (size_t)L->q_groups * 16 * blk;
-      // transposed fragments of the training sweeps, directly behind (see RsnPackedLayout)
-      int tg = L->q_groups;
-      L->t_g_begin = tg;
-      tg += 1 + 4 + 9;
-      L->t_g_trunk = tg;
-      L->t_g_encskip = -1;
-      for (int l = d->num_layers - 1; l >= 1; --l) {
-        if (l == d->skip_layer) { L->t_g_encskip = tg; tg += 4; }
-        tg += 8;
-      }
-      L->t_g_enc0 = tg;
-      tg += 4;
-      L->t_g_end = tg;
-      off += (size_t)(tg - L->q_groups) * 16 * blk;
+  }
+  if ((d->mma_mode == RSN_MMA_BF16 || d->mma_mode == RSN_MMA_BF16X6) && d->width == 256 && RSN_RING_GROUP_FRAGS == 16) {
+    // 16x32 fragments: enc 4 x 16, x 8 x 16, heads 8 x 2, bottleneck 8 x 16, mid SH 2 x 8, mid x 8 x 8, rgb 4 x 4; split-bf16:
+    // three pieces per fragment (q_pf), every count below in 16 KiB groups of PIECES
+    const int pf = d->mma_mode == RSN_MMA_BF16X6 ? 3 : 1;
+    L->q_pf = pf;
+    L->q_groups = pf * ((64 * (d->skip_layer >= 1 ? 2 : 1) + (d->num_layers - 1) * 128 + 16 + 128 + 16 + 64 + 16) / 16);
+    L->q_stream = off;
+    off += (size_t)L->q_groups * 16 * blk;
+    // transposed fragments of the training sweeps, directly behind (see RsnPackedLayout)
+    int tg = L->q_groups;
+    L->t_g_begin = tg;
+    tg += pf * (1 + 4 + 9);
+    L->t_g_trunk = tg;
+    L->t_g_encskip = -1;
+    for (int l = d->num_layers - 1; l >= 1; --l) {
+      if (l == d->skip_layer) { L->t_g_encskip = tg; tg += pf * 4; }
+      tg += pf * 8;
     }
+    L->t_g_enc0 = tg;
+    tg += pf * 4;
+    L->t_g_end = tg;
+    off += (size_t)(tg - L->q_groups) * 16 * blk;
   }
   L->total = off;
   return RSN_OK;
@@ -206,7 +211,7 @@ extern "C" int rsn_train_saved_layout(const rsn_field_desc* d, int32_t* enc_cols
   for (int s = 0; s < 128; ++s) enc_map[s] = -1;
   for (int s = 0; s < 64; ++s) sh_map[s] = -1;
   if (rsn_ring_training(d)) {  // slot s = 32 kk + 8 g + e of lane group g (rsn_field_bf16_train.hip; cols_enc16 / cols_sh16 below)
-    *enc_cols = 128; *sh_cols = 64; *narrow_bf16 = 1;
+    *enc_cols = 128; *sh_cols = 64; *narrow_bf16 = d->mma_mode == RSN_MMA_BF16 ? 1 : 0;  // split-bf16: fp32 rows
     for (int s = 0; s < 128; ++s) {
       const int kk = s >> 5, g = (s >> 3) & 3, e = s & 7, u = kk * 8 + e;
       if (u < 12) enc_map[s] = (u / 4) * 16 + 4 * g + (u % 4);
@@ -257,7 +262,7 @@ struct PackJob {
 };
 
 __device__ __forceinline__ void pack_elem(const PackJob& job, int e) {
-  if (job.layout == 1) {  // one bf16 of a 16x32 fragment: row 16 b + (lane & 15), k = 32 kk + 8 (lane >> 4) + el
+  if (job.layout >= 1) {  // one bf16 of a 16x32 fragment: row 16 b + (lane & 15), k = 32 kk + 8 (lane >> 4) + el
     if (e >= job.n_it * job.nbo * 512) return;
     const int el = e & 7, lane = (e >> 3) & 63, frag = e >> 9;
     const int b = frag % job.nbo, kk = frag / job.nbo;
@@ -270,6 +275,15 @@ __device__ __forceinline__ void pack_elem(const PackJob& job, int e) {
     } else if (rs >= 0 && c >= 0) {
       v = job.transpose ? job.src[rs][(size_t)c * job.ld[rs] + job.row_idx[n]]
                         : job.src[rs][(size_t)job.row_idx[n] * job.ld[rs] + c];
+    }
+    if (job.layout == 2) {  // split-bf16: the fragment as three pieces -- lo, mid, hi parts of v (v = hi + mid + lo up to 2^-24)
+      const __bf16 b1 = (__bf16)v;
+      const float r1 = v - (float)b1;
+      const __bf16 b2 = (__bf16)r1;
+      const __bf16 b3 = (__bf16)(r1 - (float)b2);
+      __bf16* d3 = reinterpret_cast<__bf16*>(job.dst) + (size_t)frag * 1536 + (e & 511);
+      d3[0] = b3; d3[512] = b2; d3[1024] = b1;
+      return;
     }
     reinterpret_cast<__bf16*>(job.dst)[e] = (__bf16)v;
     return;
@@ -481,7 +495,7 @@ int launch(const PackJob& j, hipStream_t st) {
     g_collect->jobs.push_back(j);
     return RSN_OK;
   }
-  const int total = j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout == 1 ? 512 : 256);
+  const int total = j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout >= 1 ? 512 : 256);
   const int threads = 256;
   hipLaunchKernelGGL(rsn_pack_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, j);
   RSN_HIP(hipGetLastError());
@@ -687,8 +701,8 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
       }
     };
     auto qpiece = [&](PackJob& jj, int ks, int nbo16) -> int {
-      jj.layout = 1; jj.n_it = ks; jj.nbo = nbo16;
-      jj.dst = packed + L.q_stream + (size_t)frag * 256;
+      jj.layout = L.q_pf == 3 ? 2 : 1; jj.n_it = ks; jj.nbo = nbo16;
+      jj.dst = packed + L.q_stream + (size_t)frag * 256 * L.q_pf;
       frag += ks * nbo16;
       return launch(jj, st);
     };
@@ -725,7 +739,7 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     for (int c = 0; c < 3; ++c) { j.row_src[4 + c] = 0; j.row_idx[4 + c] = (int16_t)c; }
     cols_x16(j, d->mid_width, 0);
     if ((rc = qpiece(j, 4, 4)) != RSN_OK) return rc;
-    RSN_REQUIRE(frag == L.q_groups * 16, RSN_ERR_INVALID_ARGUMENT, "16x32 stream: %d fragments, layout says %d groups",
+    RSN_REQUIRE(frag * L.q_pf == L.q_groups * 16, RSN_ERR_INVALID_ARGUMENT, "16x32 stream: %d fragments, layout says %d groups",
                 frag, L.q_groups);
     // ---- transposed pieces (training sweeps): packed ROW 16 b + 4 g + r <- input feature r16_feature (source COLUMN), packed
     //      K natural <- output feature (source ROW); transpose = 1 (see above: row_idx selects the source column)
@@ -789,7 +803,7 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     clear_job(j);
     j.transpose = 1; j.src[0] = p->trunk_w[0]; j.ld[0] = RSN_ENC_DIM; rowsT_enc16(j); cols_natural(j, W, 0);
     if ((rc = qpiece(j, 8, 8)) != RSN_OK) return rc;
-    RSN_REQUIRE(frag == L.t_g_end * 16, RSN_ERR_INVALID_ARGUMENT, "transposed 16x32 stream: %d fragments, layout says %d groups",
+    RSN_REQUIRE(frag * L.q_pf == L.t_g_end * 16, RSN_ERR_INVALID_ARGUMENT, "transposed 16x32 stream: %d fragments, layout says %d groups",
                 frag, L.t_g_end);
   }
 
@@ -880,14 +894,14 @@ extern "C" int rsn_pack_weights_table(const rsn_field_desc* d, const rsn_field_p
       const PackJob& j = col.jobs[i];
       host_table.block_start[i] = blocks;
       host_table.jobs[i] = j;
-      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout == 1 ? 512 : 256)) + 255) / 256;
+      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout >= 1 ? 512 : 256)) + 255) / 256;
     }
     host_table.block_start[host_table.n_jobs] = blocks;
     host_table.n_blocks = blocks;
     RSN_HIP(hipMemcpyAsync(table, &host_table, sizeof(PackTable), hipMemcpyHostToDevice, st));
   } else {
     for (const PackJob& j : col.jobs)
-      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout == 1 ? 512 : 256)) + 255) / 256;
+      blocks += ((j.is_bias ? j.n_rows : j.n_it * j.nbo * (j.layout >= 1 ? 512 : 256)) + 255) / 256;
   }
   hipLaunchKernelGGL(rsn_pack_all_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const PackTable*)table);
   RSN_HIP(hipGetLastError());

@@ -20,7 +20,7 @@
 #include "rsn_ring16.h"
 void rsn_set_error(const char*, ...) {}
 
-#define LAYERS 64             // 256 x 256 layers per tile-pass (the stream wraps around a 7-layer block)
+#define LAYERS 63             // 256 x 256 layers per tile-pass (the stream wraps around a 7-layer block)
 #define STREAM_GROUPS (7 * 8)  // 7 layers x 128 fragments = 56 groups of 16 KiB: 0.9 MB, L2-resident like the product's 1.3 MB
 
 template <int variant>
@@ -53,6 +53,59 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(const float* __restrict__
           acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][1], acc[b][1], 0, 0, 0);
         }
       }
+  } else if (variant == 2) {
+    // C: the split-bf16 (bf16x6) ring loop: every fp32 weight fragment travels as three bf16 pieces (hi, mid, lo: 3 KiB), a wave
+    // holds ONE 16-point half with its activations split three ways (96 VGPRs) and issues hi x {hi, mid, lo}, mid x {hi, mid},
+    // lo x hi = 6 MFMAs per fragment: the same two MFMAs per 1 KiB ds_read_b128 as the plain-bf16 loop
+    Ring r;
+    r.src = reinterpret_cast<const char*>(stream) + wid * (RingCfg<8>::PPW * 1024);
+    r.lane16 = (unsigned)lane * 16u;
+    r.lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wid * (RingCfg<8>::PPW * 1024u);
+    r.n_groups = STREAM_GROUPS;
+    r.issue_grp = 0;
+    r.issue_slot = 0;
+    r.rd_base = (unsigned)lane * 16u;
+    r.next_slot = 0;
+    r.rd_next = r.rd_base;
+    r.rd_cur = r.rd_base;
+    __syncthreads();
+#pragma unroll
+    for (int gq = 0; gq < RingCfg<8>::LEAD; ++gq) ring_issue<8>(r);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(RingCfg<8>::PPW * (RingCfg<8>::LEAD - 1)) : "memory");
+    bf16x8 Wf[RING_FIFO];
+#pragma unroll
+    for (int j = 0; j < RING_FIFO; ++j) Wf[j] = *reinterpret_cast<const bf16x8*>(smem + r.rd_next + j * 1024);
+    bf16x8 X3[3][8];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) X3[s3][kk] = X[(kk + s3) & 7][s3 & 1];
+    f32x4 a1[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) a1[b] = acc[b][0];
+    for (int ps = 0; ps < passes; ++ps)
+#pragma unroll 1
+      for (int l = 0; l < LAYERS / 3; ++l) {
+#pragma unroll
+        for (int gi = 0; gi < 24; ++gi) {
+          ring_sync<8>(r);
+#pragma unroll
+          for (int f = 0; f < 16; ++f) {
+            const int i = gi * 16 + f;
+            const int fr = i / 3, s3 = i % 3, kk = fr / 16, b = fr % 16;
+            const bf16x8 wa = Wf[i % RING_FIFO];
+            const int pos = f + RING_FIFO;
+            Wf[i % RING_FIFO] = *reinterpret_cast<const bf16x8*>(smem + (pos < 16 ? r.rd_cur + pos * 1024 : r.rd_next + (pos - 16) * 1024));
+            a1[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X3[0][kk], a1[b], 0, 0, 0);
+            if (s3 < 2) a1[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X3[1][kk], a1[b], 0, 0, 0);
+            if (s3 < 1) a1[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X3[2][kk], a1[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < 16; ++b) acc[b][0] = a1[b];
   } else {
     Ring r;
     r.src = reinterpret_cast<const char*>(stream) + wid * (RingCfg<8>::PPW * 1024);
@@ -107,12 +160,13 @@ int main() {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int passes = 8;
-  double tf[2];
-  const char* names[2] = {"A pure MFMA (no ring, no LDS reads)", "B ring GEMM loop alone"};
-  for (int v = 0; v < 2; ++v) {
+  double tf[3];
+  const char* names[3] = {"A pure MFMA (no ring, no LDS reads)", "B ring GEMM loop alone", "C split-bf16 (x6) ring loop, 16 points per wave"};
+  for (int v = 0; v < 3; ++v) {
     auto launch = [&](int ps) {
       if (v == 0) hipLaunchKernelGGL(probe_kernel<0>, dim3(cus), dim3(512), 0, 0, d_stream, d_out, ps);
-      else hipLaunchKernelGGL(probe_kernel<1>, dim3(cus), dim3(512), 0, 0, d_stream, d_out, ps);
+      else if (v == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(cus), dim3(512), 0, 0, d_stream, d_out, ps);
+      else hipLaunchKernelGGL(probe_kernel<2>, dim3(cus), dim3(512), 0, 0, d_stream, d_out, ps);
     };
     launch(1);
     hipDeviceSynchronize();
@@ -127,7 +181,8 @@ int main() {
       if (ms < best) best = ms;
     }
     // per wave and layer: 128 fragments x 2 MFMAs x (16 x 16 x 32 x 2) FLOP
-    const double flop = (double)cus * 8 * passes * LAYERS * 128.0 * 2.0 * 16384.0;
+    // (C: LAYERS / 3 layers of 128 fragments x 6 MFMAs -- the same MFMA count per pass)
+    const double flop = (double)cus * 8 * passes * (v == 2 ? (LAYERS / 3) * 128.0 * 6.0 : LAYERS * 128.0 * 2.0) * 16384.0;
     tf[v] = flop / (best * 1e-3) / 1e12;
     printf("%-40s %8.3f ms  %8.1f TFLOP/s  %.3f of the 2.5 PF dense bf16 peak\n", names[v], best, tf[v], tf[v] / 2500.0);
   }
