@@ -332,7 +332,8 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
             "wgrad": 2.0 * macs["wgrad"] * n_bwd,
         }
         kern = {}
-        ring = args.mma == "bf16" and args.width == 256  # plain-bf16 training at width 256: the LDS-ring kernels
+        ring = args.mma in ("bf16", "bf16x6") and args.width == 256  # plain / split bf16 training at width 256: the LDS-ring kernels
+        rk = "x6" if args.mma == "bf16x6" else "bf16"
         mi = {"bf16x6": 1, "bf16": 3}.get(args.mma, 0)
         # plain-bf16 mode: the saved rows ARE the traffic (256 FLOP per byte of row: as much HBM- as MFMA-bound).  Algorithmic HBM
         # bytes per field point: forward writes L act rows + bottleneck (W bf16 each), mid hidden, encoded / SH inputs, raw heads,
@@ -341,7 +342,7 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
         # gradient reaches them); the weight gradients read every row once (the encoded inputs twice: layer 0 and the skip layer).
         Lw, Ww = args.layers, args.width
         row_b = 2 if args.mma == "bf16" else 4
-        enc_b, sh_b = (256, 128) if ring else (416, 160)
+        enc_b, sh_b = ((256, 128) if args.mma == "bf16" else (512, 256)) if ring else (416, 160)
         skipw = Lw > 5
         fwd_w = row_b * (Lw * Ww + Ww + MID_W) + enc_b + sh_b + 32 + 32 * (Lw + 1) + 64
         bwd_w = row_b * (Lw * Ww + Ww + MID_W) + 64 + 16
@@ -351,9 +352,9 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
                "backward": (bwd_w + bwd_r) * n_bwd + enc_b * pts("field_backward_input"),
                "wgrad": wg_r * n_bwd}
         for key, name, names in (
-                ("forward", "rsn_field_bf16_train_kernel<normals>" if ring else "rsn_field_kernel<%d,true,%d>" % (args.width // 32, mi),
+                ("forward", "rsn_field_%s_train_kernel<normals>" % rk if ring else "rsn_field_kernel<%d,true,%d>" % (args.width // 32, mi),
                  ("field_forward_train_normals", "field_forward_train")),
-                ("backward", "rsn_field_bf16_bwd_kernel<input>" if ring else "rsn_field_bwd_kernel<%d,%d>" % (args.width // 32, mi),
+                ("backward", "rsn_field_%s_bwd_kernel<input>" % rk if ring else "rsn_field_bwd_kernel<%d,%d>" % (args.width // 32, mi),
                  ("field_backward", "field_backward_input")),
                 ("wgrad", "rsn_wgrad_kernel", ("weight_grad",))):
             t_ms = sum(ms(n) for n in names)
@@ -362,9 +363,10 @@ def run_train(pkg, args, dev, rank, world, dist, share, samples, steps, warmup, 
             kern[key] = {"kernel": name, "launches_per_step": n_calls / steps, "avg_launch_ms": t_ms / max(n_calls, 1),
                          "ms_per_step": t_ms / steps, "algorithmic_flop_per_step": flop[key] / steps,
                          "achieved_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS}
-            if args.mma == "bf16":  # this mode's two rooflines: the dense bf16 MFMA peak and the HBM stream of the saved rows
+            if args.mma in ("bf16", "bf16x6"):  # these modes' two rooflines: the dense bf16 MFMA peak and the HBM stream of the saved rows
                 tbps = hbm[key] / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-                kern[key].update({"frac_of_bf16_mfma_peak": tf / BF16_MFMA_PEAK_TFLOPS,
+                issued = 6.0 if args.mma == "bf16x6" else 1.0  # split-bf16: six bf16 MFMA products per fp32 product
+                kern[key].update({"frac_of_bf16_mfma_peak": issued * tf / BF16_MFMA_PEAK_TFLOPS, "bf16_products_per_flop": issued,
                                   "algorithmic_hbm_bytes_per_step": hbm[key] / steps, "achieved_hbm_tbps": tbps,
                                   "frac_of_hbm_peak": tbps / HBM_PEAK_TBPS})
         total_flop = sum(flop.values()) / steps
@@ -704,7 +706,7 @@ def main():
                                min(max(args.warmup, 1), 3), dog, time_kernels=False)
                 x6_args = argparse.Namespace(**{**vars(args), "mma": "bf16x6"})
                 x6 = run_train(pkg, x6_args, dev, rank, world, None, share, samples, min(args.steps, 10),
-                               min(max(args.warmup, 1), 3), dog, time_kernels=False)
+                               min(max(args.warmup, 1), 3), dog, time_kernels=True)
                 bf_args = argparse.Namespace(**{**vars(args), "mma": "bf16"})
                 bf = run_train(pkg, bf_args, dev, rank, world, None, share, samples, min(args.steps, 10),
                                min(max(args.warmup, 1), 3), dog, time_kernels=True)
@@ -724,8 +726,15 @@ def main():
                                     for k, v in bf["kernels"].items()}}}
                 line["train_step_bf16x6_sweeps"] = {
                     "workload": "the headline step with the forward / backward sweeps on split-bf16 MFMA (3-way split, 6 "
-                                "products, fp32 accumulate: fp32-equivalent, opt-in); weight-gradient operands split the same way in-kernel",
-                    **{k: x6[k] for k in ("value", "unit", "ms_per_step", "steps")}}
+                                "products, fp32 accumulate: fp32-equivalent, same parity bounds as the exact path; opt-in), weights "
+                                "shared per workgroup through an LDS ring as three bf16 pieces (rsn_field_x6_train.hip); saved rows / "
+                                "layer gradients are fp32; weight-gradient operands split the same way in-kernel",
+                    **{k: x6[k] for k in ("value", "unit", "ms_per_step", "steps")},
+                    "roofline": {"note": "per kernel: ISSUED bf16 MFMA work (6 x the algorithmic FLOP) / time against the 2.5 PF dense bf16 "
+                                         "peak, and algorithmic HBM bytes of the fp32 saved rows / time against 8 TB/s",
+                                 **{k: {q: v[q] for q in ("kernel", "ms_per_step", "achieved_tflops", "frac_of_bf16_mfma_peak",
+                                                          "algorithmic_hbm_bytes_per_step", "achieved_hbm_tbps", "frac_of_hbm_peak")}
+                                    for k, v in x6["kernels"].items()}}}
                 line["train_step_configs2"] = {
                     "workload": "BASELINE configs[2]: %d rays x (64 coarse + 128 fine) + reflect 64 + 64, forward + backward "
                                 "(+ loss + RAdam)" % R,

@@ -11,13 +11,17 @@
 //     1 / 2 / 3 MFMAs (lo x hi;  mid x {mid, hi};  hi x {lo, mid, hi}: the six products of bf16x6, small ones first), i.e. the
 //     same two MFMAs per ds_read_b128 as the plain-bf16 loop (tools/probes/ring16_probe.hip variant C: 0.78 of the 2.5 PF
 //     issue peak for the loop alone);
-//   * a wave holds ONE 16-point half (128-point tiles per workgroup): its activations live as three bf16 pieces (96 VGPRs)
-//     beside 64 accumulator registers; they are split ONCE per layer in the epilogue that produces them (11 vector instructions
-//     per pair of values, 0.6 per MFMA), not once per K-step and wave;
+//   * a wave holds ONE 16-point half (128-point tiles per workgroup) and its activations stay FP32 in the accumulator registers
+//     that produced them (64 VGPRs, lane-local: blocks 2kk, 2kk+1 are the lane's share of K-step kk); the B operand of K-step
+//     kk + 1 -- ReLU / ReLU-mask, 3-way split (11 vector instructions per pair of values), ReLU bits -- is formed a pair of values
+//     at a time BETWEEN the MFMAs of K-step kk (gemm_j: 0.6 vector instructions per MFMA, none of them in an MFMA-free phase);
+//     a layer hand-off is 64 register copies.  (First version: split once per layer in an epilogue between the GEMMs -- 620 VALU
+//     and 18 stores with the matrix pipe idle, both waves of a SIMD in it together: 0.52 of the issue peak, MFMA busy 60 %.)
 //   * everything kept for the backward pass / the weight gradients is fp32 (this mode is fp32-equivalent: the same parity
 //     bounds as the exact path): a lane's share of a row -- 8 contiguous features = 32 bytes per K-step -- leaves as two
-//     non-temporal 16-byte stores from the epilogue, between the splits; encode, activations, SH and the chain through the
-//     encoding use the exact-fp32 forms of rsn_field_kernel.h (sin_big, expf, log1pf ...), not the fast ones of the bf16 mode.
+//     non-temporal 16-byte stores at the ring's group boundaries INSIDE the GEMM that reads the row; encode, activations, SH and
+//     the chain through the encoding use the exact-fp32 forms of rsn_field_kernel.h (sin_big, expf, log1pf ...), not the fast
+//     ones of the bf16 mode.
 // Saved-buffer layout: rsn_train_saved_layout (include/rsn.h): enc fp32 [N,128], sh fp32 [N,64] in the ring's slot order,
 // ReLU bit words [L+1][N][4 lane groups][2 words], wide buffers fp32 [N,W] in natural feature order.
 #include "rsn_ringt.h"
@@ -31,51 +35,68 @@
 #define X6_STASH_BYTES (8 * 1024)   // per wave: 8 float4 per lane -- the encoded inputs [kk (4)][half (2)], later the SH inputs / the
                                     // derivative factors of the encoding
 
-// the three bf16 parts of eight fp32 values (x = h + m + l exactly: 3 x 8 significant bits)
-typedef bf16x8 X3[3];   // [0] hi, [1] mid, [2] lo  (an array, not a struct: hipcc keeps arrays of them in registers)
+// the three bf16 parts of fp32 values (x = h + m + l exactly: 3 x 8 significant bits), as packed words
+typedef uint4v P3[3];   // [0] hi, [1] mid, [2] lo: dword i = the pair of values (2 i, 2 i + 1) of a K-step's eight
 #define XH_ 0
 #define XM_ 1
 #define XL_ 2
-__device__ __forceinline__ void split8(const float (&v)[8], X3& o) {
-  uint4v wh, wm, wl;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = v[2 * i], b = v[2 * i + 1];
-    const unsigned h2 = pack2<false>(a, b);
-    const float ra = a - __uint_as_float(h2 << 16), rb = b - __uint_as_float(h2 & 0xffff0000u);
-    const unsigned m2 = pack2<false>(ra, rb);
-    const float sa = ra - __uint_as_float(m2 << 16), sb = rb - __uint_as_float(m2 & 0xffff0000u);
-    wh[i] = h2;
-    wm[i] = m2;
-    wl[i] = pack2<false>(sa, sb);
-  }
-  o[XH_] = __builtin_bit_cast(bf16x8, wh);
-  o[XM_] = __builtin_bit_cast(bf16x8, wm);
-  o[XL_] = __builtin_bit_cast(bf16x8, wl);
-}
-__device__ __forceinline__ void split8(const float4 lo, const float4 hi, X3& o) {
-  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  split8(v, o);
+__device__ __forceinline__ unsigned split_pair(float a, float b, P3& o, int i) {
+  const unsigned h2 = pack2<false>(a, b);
+  const float ra = a - __uint_as_float(h2 << 16), rb = b - __uint_as_float(h2 & 0xffff0000u);
+  const unsigned m2 = pack2<false>(ra, rb);
+  const float sa = ra - __uint_as_float(m2 << 16), sb = rb - __uint_as_float(m2 & 0xffff0000u);
+  o[XH_][i] = h2;
+  o[XM_][i] = m2;
+  o[XL_][i] = pack2<false>(sa, sb);
+  return h2;
 }
 
-// acc[b] (+)= W-fragment(fr) * X[kk], fragment fr = (K-step kk, block b) arriving as the pieces lo, mid, hi (i = 3 fr + s).
-// Six products, the small ones first: lo x h | mid x m, mid x h | hi x l, hi x m, hi x h.
-template <int NBO, int KS, int XN, int INIT, class RING, class HOOK>
-__device__ __forceinline__ void gemm_x6(f32x4 (&acc)[NBO], const X3 (&X)[XN], RING& r, bf16x8 (&W)[RING_FIFO], const char* smem,
-                                        HOOK&& hook, const float* bias = nullptr, int g = 0) {
-  static_assert((NBO * KS * 3) % RSN_RING_GROUP_FRAGS == 0 && KS <= XN, "a GEMM is a whole number of ring groups");
+// acc[b] (+)= W-fragment(kk, b) * B(kk), the fragment arriving as the pieces lo, mid, hi (piece j = 3 b + s of K-step kk); six
+// products, the small ones first: lo x h | mid x m, mid x h | hi x l, hi x m, hi x h.
+// The B operand is formed JUST IN TIME: src(kk, i, a, b) yields the pair of fp32 values (2 i, 2 i + 1) of K-step kk (the caller's
+// ReLU / mask applied); the four pairs of K-step kk + 1 are split at the quarter points of K-step kk's pieces, under its MFMAs
+// (two operand buffers); note(kk, i, hi word) sees every pair's hi part (ReLU bits).  hook(group) runs behind every ring boundary.
+struct NoNote {
+  __device__ __forceinline__ void operator()(int, int, unsigned) const {}
+};
+template <int NBO, int KS, int INIT, class SRC, class NOTE, class RING, class HOOK>
+__device__ __forceinline__ void gemm_j(f32x4 (&acc)[NBO], SRC&& src, NOTE&& note, RING& r, bf16x8 (&W)[RING_FIFO], const char* smem,
+                                       HOOK&& hook, const float* bias = nullptr, int g = 0) {
+  constexpr int PK = NBO * 3;  // pieces per K-step
+  static_assert((PK * KS) % RSN_RING_GROUP_FRAGS == 0, "a GEMM is a whole number of ring groups");
+  P3 P[2];
 #pragma unroll
-  for (int gi = 0; gi < NBO * KS * 3 / RSN_RING_GROUP_FRAGS; ++gi) {
+  for (int q = 0; q < 4; ++q) {  // K-step 0's operand: nothing of this GEMM to hide it under
+    float a, b;
+    src(0, q, a, b);
+    note(0, q, split_pair(a, b, P[0], q));
+  }
+#pragma unroll
+  for (int gi = 0; gi < PK * KS / RSN_RING_GROUP_FRAGS; ++gi) {
     ringt_sync(r);
     hook(gi);
 #pragma unroll
     for (int f = 0; f < RSN_RING_GROUP_FRAGS; ++f) {
       const int i = gi * RSN_RING_GROUP_FRAGS + f;
-      const int fr = i / 3, s = i % 3, kk = fr / NBO, b = fr % NBO;
+      const int kk = i / PK, j = i % PK, b = j / 3, s = j % 3;
       const bf16x8 wa = W[i % RING_FIFO];
       const int pos = f + RING_FIFO;
       W[i % RING_FIFO] = *reinterpret_cast<const bf16x8*>(
           smem + (pos < RSN_RING_GROUP_FRAGS ? r.rd_cur + pos * 1024 : r.rd_next + (pos - RSN_RING_GROUP_FRAGS) * 1024));
+#ifndef RSN_RT_NO_PREP  // (timing ablation: every K-step multiplies K-step 0's operand)
+      constexpr int pb = 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (kk + 1 < KS && j == (q * PK) / 4) {
+          float a, b2;
+          src(kk + 1, q, a, b2);
+          note(kk + 1, q, split_pair(a, b2, P[(kk + 1) & 1], q));
+        }
+#else
+      constexpr int pb = 0;
+#endif
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, P[kk & pb][XH_]), xm = __builtin_bit_cast(bf16x8, P[kk & pb][XM_]),
+                   xl = __builtin_bit_cast(bf16x8, P[kk & pb][XL_]);
       if (s == 0) {
         f32x4 c = acc[b];
         if (INIT != GI_ACC && kk == 0) {
@@ -85,14 +106,14 @@ __device__ __forceinline__ void gemm_x6(f32x4 (&acc)[NBO], const X3 (&X)[XN], RI
             c = f32x4{bv.x, bv.y, bv.z, bv.w};
           }
         }
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][XH_], c, 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, c, 0, 0, 0);
       } else if (s == 1) {
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][XM_], acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][XH_], acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xm, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, acc[b], 0, 0, 0);
       } else {
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][XL_], acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][XM_], acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, X[kk][XH_], acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xl, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xm, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, acc[b], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -104,7 +125,10 @@ template <class RING>
 __device__ __forceinline__ void st16f(const RowD& d, unsigned voff, unsigned soff, float a, float b, float c, float e, RING& r) {
 #ifndef RSN_RT_NO_STORES
   const u32x4t v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(e)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, d.r, voff, soff, RT_STORE_AUX);
+  // the constant part goes into the instruction's immediate offset, the scalar offset stays 0: with a REGISTER soffset the
+  // compiler's hazard recogniser assumes that a VALU may overwrite the store's data registers in the very next instruction --
+  // on gfx950 it may not (measured: the last quarter of every 16 lanes stored the overwriting value); see st16 (rsn_ringt.h)
+  __builtin_amdgcn_raw_buffer_store_b128(v, d.r, voff + soff, 0, RT_STORE_AUX);
 #ifndef RSN_RT_UNCOUNTED
   r.c0 += 1;
   r.since += 1;
@@ -127,62 +151,69 @@ __device__ __forceinline__ void tie8(u32x4t (&q)[8]) {
   for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(q[i])::"memory");
 }
 
-// Epilogue of a GEMM whose result feeds another GEMM: blocks 2kk, 2kk+1 = the lane's features 32 kk + 8 g .. + 7 of its point
-// -> (ReLU) -> the fp32 row piece leaves (32 bytes at 128 kk + 32 g of the row) -> split into the next B operand.
-template <bool RELU, int NKS, int NBO, int XN, class RING>
-__device__ __forceinline__ void epi_rows(const f32x4 (&acc)[NBO], X3 (&X)[XN], const RowD& d, unsigned voff, RING& r) {
+// The row piece of K-step kk (the lane's features 32 kk + 8 g .. + 7 of its point: 32 bytes at 128 kk + 32 g of the row) leaves ...
+template <class SRC, class RING>
+__device__ __forceinline__ void store_kstep(const RowD& d, unsigned voff, int kk, SRC&& src, RING& r) {
+  float v[8];
 #pragma unroll
-  for (int kk = 0; kk < NKS; ++kk) {
-    float v[8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[4 * t + q] = RELU ? relu_f(acc[2 * kk + t][q]) : acc[2 * kk + t][q];
-    st16f(d, voff, kk * 128, v[0], v[1], v[2], v[3], r);
-    st16f(d, voff, kk * 128 + 16, v[4], v[5], v[6], v[7], r);
-    split8(v, X[kk]);
-  }
+  for (int i = 0; i < 4; ++i) src(kk, i, v[2 * i], v[2 * i + 1]);
+  st16f(d, voff, kk * 128, v[0], v[1], v[2], v[3], r);
+  st16f(d, voff, kk * 128 + 16, v[4], v[5], v[6], v[7], r);
 }
-// the same for a layer gradient: masked by the ReLU bits of the layer it enters (bit layout: relu_bits3 below)
-template <bool STORE, int NKS, int NBO, int XN, class RING>
-__device__ __forceinline__ void epi_masked(const f32x4 (&acc)[NBO], X3 (&X)[XN], const unsigned (&bits)[2], const RowD& d,
-                                           unsigned voff, RING& r) {
+// ... at the group boundary in front of its first piece, inside the GEMM that reads the row (PK pieces per K-step)
+template <int PK, int KS, class SRC, class RING>
+__device__ __forceinline__ void hook_rows(int gi, const RowD& d, unsigned voff, SRC&& src, RING& r) {
 #pragma unroll
-  for (int kk = 0; kk < NKS; ++kk) {
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = (kk & 3) * 4 + (e >> 1), pos = ((e & 1) ? 31 : 15) - j;
+  for (int kk = 0; kk < KS; ++kk)
+    if ((kk * PK) / RSN_RING_GROUP_FRAGS == gi) store_kstep(d, voff, kk, src, r);
+}
+
+// sources of a GEMM's B operand from the accumulators of the GEMM before it: blocks 2 kk, 2 kk + 1 hold K-step kk's eight values
+template <bool RELU, int NB>
+struct SrcAcc {
+  const f32x4 (&A)[NB];
+  __device__ __forceinline__ void operator()(int kk, int i, float& a, float& b) const {
+    const f32x4 v = A[2 * kk + (i >> 1)];
+    a = v[2 * (i & 1)];
+    b = v[2 * (i & 1) + 1];
+    if (RELU) {
+      a = relu_f(a);
+      b = relu_f(b);
+    }
+  }
+};
+// a layer gradient: masked by the ReLU bits of the layer it enters (bit layout: BitsNote below)
+template <int NB>
+struct SrcMasked {
+  const f32x4 (&A)[NB];
+  const unsigned (&bits)[2];
+  __device__ __forceinline__ void operator()(int kk, int i, float& a, float& b) const {
+    const f32x4 v = A[2 * kk + (i >> 1)];
+    const int j = (kk & 3) * 4 + i;
 #ifdef RSN_RT_NO_BITS
-      const int mk = -1;
+    const int ma = -1, mb = -1;
 #else
-      const int mk = __builtin_amdgcn_sbfe((int)bits[kk >> 2], (unsigned)pos, 1u);  // 0 or -1
+    const int ma = __builtin_amdgcn_sbfe((int)bits[kk >> 2], (unsigned)(15 - j), 1u);  // 0 or -1
+    const int mb = __builtin_amdgcn_sbfe((int)bits[kk >> 2], (unsigned)(31 - j), 1u);
 #endif
-      v[e] = __uint_as_float(__float_as_uint(acc[2 * kk + (e >> 2)][e & 3]) & (unsigned)mk);
-    }
-    if (STORE) {
-      st16f(d, voff, kk * 128, v[0], v[1], v[2], v[3], r);
-      st16f(d, voff, kk * 128 + 16, v[4], v[5], v[6], v[7], r);
-    }
-    split8(v, X[kk]);
+    a = __uint_as_float(__float_as_uint(v[2 * (i & 1)]) & (unsigned)ma);
+    b = __uint_as_float(__float_as_uint(v[2 * (i & 1) + 1]) & (unsigned)mb);
   }
-}
-// ReLU bits of the post-ReLU activations X[kk0 .. kk0+3] (from their hi parts: hi > 0 <=> value > 0): word j = 4 (kk - kk0) + wi
-// contributes (low half > 0) at bit 15 - j and (high half > 0) at bit 31 - j -- the layout of rsn_field_bf16_train.hip
-template <int XN>
-__device__ __forceinline__ unsigned relu_bits3(const X3 (&X)[XN], int kk0, unsigned one2) {
+};
+// ReLU bits of post-ReLU values from the hi parts of their splits (hi > 0 <=> value > 0): the pair i of K-step kk is word
+// j = 4 (kk & 3) + i of bits[kk >> 2]: (low half > 0) at bit 15 - j, (high half > 0) at bit 31 - j -- the layout of
+// rsn_field_bf16_train.hip.  Pairs arrive in ascending (kk, i).
+struct BitsNote {
+  unsigned (&bw)[2];
+  __device__ __forceinline__ void operator()(int kk, int i, unsigned h2) const {
 #ifdef RSN_RT_NO_BITS
-  return 0xffffffffu;
+    bw[kk >> 2] = 0xffffffffu;
+#else
+    const unsigned t = pk_min_u16(h2, 0x00010001u);
+    bw[kk >> 2] = ((kk & 3) == 0 && i == 0) ? t : ((bw[kk >> 2] << 1) | t);
 #endif
-  unsigned b = 0u;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint4v w = __builtin_bit_cast(uint4v, X[kk0 + (j >> 2)][XH_]);
-    const unsigned t = pk_min_u16(w[j & 3], one2);
-    b = (j == 0) ? t : ((b << 1) | t);
   }
-  return b;
-}
+};
 
 // Gradient w.r.t. this lane's encoded inputs (eacc: packed rows 16 b + 4 g + r = slot (kk = b / 2, e = 4 (b % 2) + r); slot
 // u = 8 kk + e: u < 12 the sine feature of (coordinate u / 4, frequency 4 g + u % 4), 12 <= u < 24 its cosine feature, 24..26 the
@@ -205,6 +236,11 @@ __device__ __forceinline__ void fold_enc3(const f32x4 (&eacc)[8], const float (&
     part[c] += s;
     if (NORMALS) raw[c] += eacc[6][c];  // slot u = 24 + c: kk = 3, e = c (meaningful on g == 0 only)
   }
+}
+template <int NB>
+__device__ __forceinline__ void copy_acc(f32x4 (&dst)[NB], const f32x4 (&src)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) dst[b] = src[b];
 }
 
 // ================================================================================================ training forward
@@ -238,7 +274,6 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
   bf16x8 Wf[RING_FIFO];
   // the walk: forward stream [0, q_groups); with the normal sweep then [t_g_trunk, t_g_end) of the transposed stream; again
   ring_start(r, pk, P.L, smem, wid, lane, 0, P.L.q_groups, NORMALS ? P.L.t_g_trunk : 0, NORMALS ? P.L.t_g_end : -1, 0, Wf);
-  const unsigned one2 = 0x00010001u;
 
   for (long long gtile = blockIdx.x; gtile < T.n_tiles; gtile += gridDim.x) {
     const int jk = (gtile >= T.tb1 ? 1 : 0) + (gtile >= T.tb2 ? 1 : 0);  // workgroup-uniform
@@ -287,12 +322,17 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
 
     auto d_act = [&](int l) { return rowd(a.saved.act, ((long long)l * n_max + p0) * 1024, rows, 1024); };
     auto d_bits = [&](int l) { return rowd(a.saved.relu_bits, ((long long)l * n_max + p0) * 32, rows, 32); };
+    // the encoded inputs / SH inputs as a GEMM source: the lane's float4 slots 2 kk, 2 kk + 1 of the stash
+    auto src_stash = [&](int kk, int i, float& x, float& y) {
+      const float4 q = ST[(2 * kk + (i >> 1)) * 64];
+      x = (i & 1) ? q.z : q.x;
+      y = (i & 1) ? q.w : q.y;
+    };
 
-    X3 X[8];
+    f32x4 A[16];      // the pre-activation of the trunk layer just finished (ReLU is applied where it is consumed)
     unsigned bwe[2];  // the embedding's ReLU bits: the seed mask of the normal sweep
     // ---------------- trunk -----------------
     {
-      f32x4 acc[16];
       {
         float feat[32];
 #pragma unroll
@@ -318,35 +358,29 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
           ST[(2 * kk + 1) * 64] = make_float4(feat[8 * kk + 4], feat[8 * kk + 5], feat[8 * kk + 6], feat[8 * kk + 7]);
           st16f(d_enc, vrow * 512 + 32 * g, kk * 128, feat[8 * kk], feat[8 * kk + 1], feat[8 * kk + 2], feat[8 * kk + 3], r);
           st16f(d_enc, vrow * 512 + 32 * g, kk * 128 + 16, feat[8 * kk + 4], feat[8 * kk + 5], feat[8 * kk + 6], feat[8 * kk + 7], r);
-          const float v8[8] = {feat[8 * kk], feat[8 * kk + 1], feat[8 * kk + 2], feat[8 * kk + 3],
-                               feat[8 * kk + 4], feat[8 * kk + 5], feat[8 * kk + 6], feat[8 * kk + 7]};
-          split8(v8, X[kk]);
         }
+        gemm_j<16, 4, GI_BIAS>(A, [&](int kk, int i, float& x, float& y) { x = feat[8 * kk + 2 * i]; y = feat[8 * kk + 2 * i + 1]; },
+                               NoNote(), r, Wf, smem, NoHook(), bias, g);
       }
-      gemm_x6<16, 4, 8, GI_BIAS>(acc, X, r, Wf, smem, NoHook(), bias, g);
 #pragma unroll 1
       for (int l = 1; l < L; ++l) {
-        epi_rows<true, 8>(acc, X, d_act(l - 1), vrow * 1024 + 32 * g, r);   // X = act[l-1] (post-ReLU); its rows leave here
-        st8(d_bits(l - 1), vrow * 32 + 8 * g, 0, relu_bits3<8>(X, 0, one2), relu_bits3<8>(X, 4, one2), r);
-        gemm_x6<16, 8, 8, GI_BIAS>(acc, X, r, Wf, smem, NoHook(), bias + l * 256, g);
-        if (l == P.skip_layer) {
-          X3 XE[4];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) split8(ST[(2 * kk) * 64], ST[(2 * kk + 1) * 64], XE[kk]);
-          gemm_x6<16, 4, 4, GI_ACC>(acc, XE, r, Wf, smem, NoHook());
-        }
+        f32x4 B[16];
+        unsigned bw[2] = {0u, 0u};
+        const RowD da = d_act(l - 1);
+        const SrcAcc<true, 16> sa{A};   // act[l-1] = ReLU(A): its rows leave from the GEMM that reads it, one K-step per three groups
+        gemm_j<16, 8, GI_BIAS>(B, sa, BitsNote{bw}, r, Wf, smem,
+                               [&](int gi) { hook_rows<48, 8>(gi, da, vrow * 1024 + 32 * g, sa, r); }, bias + l * 256, g);
+        st8(d_bits(l - 1), vrow * 32 + 8 * g, 0, bw[0], bw[1], r);
+        if (l == P.skip_layer) gemm_j<16, 4, GI_ACC>(B, src_stash, NoNote(), r, Wf, smem, NoHook());
+        copy_acc(A, B);
       }
-      epi_rows<true, 8>(acc, X, d_act(L - 1), vrow * 1024 + 32 * g, r);  // out_activation = ReLU: the embedding = act[L-1]
-      bwe[0] = relu_bits3<8>(X, 0, one2);
-      bwe[1] = relu_bits3<8>(X, 4, one2);
-      st8(d_bits(L - 1), vrow * 32 + 8 * g, 0, bwe[0], bwe[1], r);
     }
 
-    // ---------------- heads: one 16-row block (+ a zero block) -----------------
+    // ---------------- heads: one 16-row block (+ a zero block) on the embedding = ReLU(A) -----------------
     float dcol[3];
     {
       f32x4 acch[2];
-      gemm_x6<2, 8, 8, GI_BIAS>(acch, X, r, Wf, smem, NoHook(), b_bh + 256, g);
+      gemm_j<2, 8, GI_BIAS>(acch, SrcAcc<true, 16>{A}, BitsNote{bwe}, r, Wf, smem, NoHook(), b_bh + 256, g);
       const float r0 = acch[0][0], r1 = acch[0][1], r2 = acch[0][2], r3 = acch[0][3];
       // g == 0: r0 raw density, r1..r3 normals;  g == 1: r0..r2 diff;  g == 2: r0 roughness;  g == 3: r0..r2 tint
       const float rough_raw = __shfl(r0, 32 + m, 64);
@@ -368,6 +402,10 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
           ST[3 * 64 + gq * 16] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
       }
+      // the other lanes of the point read these slots: hipcc sees only this lane's addresses (constant offsets it can tell apart) and
+      // would be free to move a later read of ST[k * 64] above the writes; the wave's LDS operations execute in program order
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
       dcol[0] = sigmoid_f(r0); dcol[1] = sigmoid_f(r1); dcol[2] = sigmoid_f(r2);
       if (valid) {
         const size_t q = pc;
@@ -404,34 +442,26 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
         }
       }
     }
-    // ---------------- bottleneck -----------------
+    // ---------------- bottleneck (the embedding's rows and bits leave from this GEMM), mlp_mid, RGB head -----------------
     {
-      f32x4 acc[16];
-      gemm_x6<16, 8, 8, GI_BIAS>(acc, X, r, Wf, smem, NoHook(), b_bh, g);
-      // bottleneck output (no activation): the x-part of mlp_mid's input; its rows leave here
-      epi_rows<false, 8>(acc, X, rowd(a.saved.bott, (long long)p0 * 1024, rows, 1024), vrow * 1024 + 32 * g, r);
-    }
-
-    // ---------------- mlp_mid + RGB head -----------------
-    {
-      f32x4 accm[8];
-      X3 XS[2];
+      f32x4 Bt[16];  // bottleneck output (no activation): the x-part of mlp_mid's input
       {
-        const float4 s0 = ST[0 * 64], s1 = ST[1 * 64], s2 = ST[2 * 64], s3 = ST[3 * 64];
-        const RowD d_sh = rowd(a.saved.sh, (long long)p0 * 256, rows, 256);   // fp32 [N,64]
-        st16f(d_sh, vrow * 256 + 32 * g, 0, s0.x, s0.y, s0.z, s0.w, r);
-        st16f(d_sh, vrow * 256 + 32 * g, 16, s1.x, s1.y, s1.z, s1.w, r);
-        st16f(d_sh, vrow * 256 + 32 * g, 128, s2.x, s2.y, s2.z, s2.w, r);
-        st16f(d_sh, vrow * 256 + 32 * g, 144, s3.x, s3.y, s3.z, s3.w, r);
-        split8(s0, s1, XS[0]);
-        split8(s2, s3, XS[1]);
+        const RowD da = d_act(L - 1);
+        const SrcAcc<true, 16> sa{A};
+        gemm_j<16, 8, GI_BIAS>(Bt, sa, NoNote(), r, Wf, smem, [&](int gi) {
+          hook_rows<48, 8>(gi, da, vrow * 1024 + 32 * g, sa, r);
+          if (gi == 0) st8(d_bits(L - 1), vrow * 32 + 8 * g, 0, bwe[0], bwe[1], r);
+        }, b_bh, g);
       }
-      gemm_x6<8, 2, 2, GI_BIAS>(accm, XS, r, Wf, smem, NoHook(), b_mid, g);
-      gemm_x6<8, 8, 8, GI_ACC>(accm, X, r, Wf, smem, NoHook());
-      epi_rows<true, 4>(accm, X, rowd(a.saved.hid, (long long)p0 * 512, rows, 512), vrow * 512 + 32 * g, r);  // hidden (128): K-steps 0..3
-      st8(d_bits(L), vrow * 32 + 8 * g, 0, relu_bits3<8>(X, 0, one2), 0u, r);
-    }
-    {
+      f32x4 accm[8];
+      {
+        const RowD d_sh = rowd(a.saved.sh, (long long)p0 * 256, rows, 256);   // fp32 [N,64]
+        gemm_j<8, 2, GI_BIAS>(accm, src_stash, NoNote(), r, Wf, smem,
+                              [&](int gi) { hook_rows<24, 2>(gi, d_sh, vrow * 256 + 32 * g, src_stash, r); }, b_mid, g);
+        const RowD d_bott = rowd(a.saved.bott, (long long)p0 * 1024, rows, 1024);
+        const SrcAcc<false, 16> sb{Bt};
+        gemm_j<8, 8, GI_ACC>(accm, sb, NoNote(), r, Wf, smem, [&](int gi) { hook_rows<24, 8>(gi, d_bott, vrow * 1024 + 32 * g, sb, r); });
+      }
       f32x4 accr[4];  // block 0 carries the RGB rows 4..6; blocks 1..3 are whole-group padding
       {
         const float4 bv = *reinterpret_cast<const float4*>(b_rgb + 4 * g);
@@ -440,7 +470,13 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
 #pragma unroll
         for (int b = 1; b < 4; ++b) accr[b] = z;
       }
-      gemm_x6<4, 4, 8, GI_ACC>(accr, X, r, Wf, smem, NoHook());
+      unsigned bwh[2] = {0u, 0u};
+      {
+        const RowD d_hid = rowd(a.saved.hid, (long long)p0 * 512, rows, 512);   // hidden (128): K-steps 0..3 = ReLU(accm)
+        const SrcAcc<true, 8> sh_{accm};
+        gemm_j<4, 4, GI_ACC>(accr, sh_, BitsNote{bwh}, r, Wf, smem, [&](int gi) { hook_rows<12, 4>(gi, d_hid, vrow * 512 + 32 * g, sh_, r); });
+        st8(d_bits(L), vrow * 32 + 8 * g, 0, bwh[0], 0u, r);
+      }
       const float m0 = sigmoid_f(accr[0][0]), m1 = sigmoid_f(accr[0][1]), m2 = sigmoid_f(accr[0][2]);
       const float t0 = __shfl(dcol[0], 48 + m, 64), t1 = __shfl(dcol[1], 48 + m, 64), t2 = __shfl(dcol[2], 48 + m, 64);
       if (g == 1 && valid) {
@@ -483,22 +519,21 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
 #pragma unroll
         for (int i = 0; i < 6; ++i) ST[i * 64] = make_float4(df[4 * i], df[4 * i + 1], df[4 * i + 2], df[4 * i + 3]);
       }
-      // seed: the density-head row masked by the embedding's ReLU
-      {
-        f32x4 sd[16];
+      // G: the gradient entering layer l's output BEFORE that layer's ReLU mask bm (applied where it is consumed).  Seed: the
+      // density-head row, masked by the embedding's ReLU
+      f32x4 G[16];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const float4 lo = *reinterpret_cast<const float4*>(vden + 32 * kk + 8 * g);
-          const float4 hi = *reinterpret_cast<const float4*>(vden + 32 * kk + 8 * g + 4);
-          sd[2 * kk] = f32x4{lo.x, lo.y, lo.z, lo.w};
-          sd[2 * kk + 1] = f32x4{hi.x, hi.y, hi.z, hi.w};
-        }
-        epi_masked<false, 8>(sd, X, bwe, RowD{}, 0u, r);
+      for (int kk = 0; kk < 8; ++kk) {
+        const float4 lo = *reinterpret_cast<const float4*>(vden + 32 * kk + 8 * g);
+        const float4 hi = *reinterpret_cast<const float4*>(vden + 32 * kk + 8 * g + 4);
+        G[2 * kk] = f32x4{lo.x, lo.y, lo.z, lo.w};
+        G[2 * kk + 1] = f32x4{hi.x, hi.y, hi.z, hi.w};
       }
+      unsigned bm[2] = {bwe[0], bwe[1]};
       float part[3] = {0.0f, 0.0f, 0.0f}, raw[3] = {0.0f, 0.0f, 0.0f};
       auto enc_part = [&]() {  // eacc = (encoded-input part)^T x gradient, folded at once with the derivative factors
         f32x4 eacc[8];
-        gemm_x6<8, 8, 8, GI_ZERO>(eacc, X, r, Wf, smem, NoHook());
+        gemm_j<8, 8, GI_ZERO>(eacc, SrcMasked<16>{G, bm}, NoNote(), r, Wf, smem, NoHook());
         float df[24];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -514,11 +549,11 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
         u32x2t b0 = ald8(db, vrow * 32 + 8 * g);
         r.since = 0;
         f32x4 acc[16];
-        gemm_x6<16, 8, 8, GI_ZERO>(acc, X, r, Wf, smem, NoHook());
+        gemm_j<16, 8, GI_ZERO>(acc, SrcMasked<16>{G, bm}, NoNote(), r, Wf, smem, NoHook());
         wait_loads(r);
         tie1(b0);
-        const unsigned bm[2] = {b0.x, b0.y};
-        epi_masked<false, 8>(acc, X, bm, RowD{}, 0u, r);
+        bm[0] = b0.x; bm[1] = b0.y;
+        copy_acc(G, acc);
       }
       enc_part();
       float nrm[3];
@@ -564,7 +599,6 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
     else { e0 = Y.t_g_enc0; j0 = Y.t_g_begin; e1 = -1; j1 = 0; }
     ring_start(r, pk, Y, smem, wid, lane, Y.t_g_begin, e0, j0, e1, j1, Wf);
   }
-  const float z8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
   for (long long gtile = blockIdx.x; gtile < T.n_tiles; gtile += gridDim.x) {
     const int jk = (gtile >= T.tb1 ? 1 : 0) + (gtile >= T.tb2 ? 1 : 0);  // workgroup-uniform
@@ -581,9 +615,8 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
     auto d_dy = [&](int l) { return rowd(a.gout.dy, ((long long)l * n_max + p0) * 1024, rows, 1024); };
 
     // ---------------- per-sample epilogue gradients (reference autograd restated: see rsn_field_bwd.hip) -----------------
-    X3 X[8];
-    X3 XH;   // heads pre-activation gradients as the ninth K-step of the [bottleneck; heads]^T GEMM
-    X3 X0;   // RGB-head pre-activation gradient
+    float dz[3];                                       // RGB-head pre-activation gradient
+    float4 qh = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // heads pre-activation gradients, rows 4 g + r
     {
       const unsigned pt = p0 + m;
       const bool valid = pt < n_points;
@@ -605,27 +638,21 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
           tin[c] = a.fwd.tint[q * 3 + c];
         }
       }
-      float dz[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) dz[c] = gcol[c] * tin[c] * (mid[c] * (1.0f - mid[c]));
       if (g == 1 && valid && a.gout.dz_rgb) *reinterpret_cast<float4*>(a.gout.dz_rgb + q * 4) = make_float4(dz[0], dz[1], dz[2], 0.0f);
-      {
-        const float v[8] = {g == 1 ? dz[0] : 0.0f, g == 1 ? dz[1] : 0.0f, g == 1 ? dz[2] : 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        split8(v, X0);
-      }
-      float4 qh = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // heads rows 4 g + r
       if (a.mode != RSN_MODE_INF) {
         if (g == 0) {
           const long long ray = (long long)(q / (unsigned)a.S);
           const float rawd = a.fwd.raw_density[q];
           const float gs = a.gin.sigma ? a.gin.sigma[q] * live : 0.0f;
           qh.x = gs * sigmoid_f(rawd + P.density_bias);  // softplus'
-          float dir[3], G[3] = {0.0f, 0.0f, 0.0f};
+          float dir[3], G3[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
           for (int c = 0; c < 3; ++c) dir[c] = a.directions[ray * 3 + c];
           if (a.gin.pred_normals) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) G[c] = a.gin.pred_normals[q * 3 + c] * live;
+            for (int c = 0; c < 3; ++c) G3[c] = a.gin.pred_normals[q * 3 + c] * live;
           }
           float gd = a.gin.n_dot_d ? a.gin.n_dot_d[q] * live : 0.0f;
           if (a.gin.ray_pn_loss || a.gin.ray_ori_loss) {  // fused normal losses (model.py:403-407)
@@ -633,17 +660,17 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
             if (a.gin.ray_pn_loss) {
               const float gw = a.gin.ray_pn_loss[ray] * w * -2.0f;
 #pragma unroll
-              for (int c = 0; c < 3; ++c) G[c] += gw * (a.saved.normals[q * 3 + c] - a.fwd.pred_normals[q * 3 + c]);
+              for (int c = 0; c < 3; ++c) G3[c] += gw * (a.saved.normals[q * 3 + c] - a.fwd.pred_normals[q * 3 + c]);
             }
             if (a.gin.ray_ori_loss) gd += a.gin.ray_ori_loss[ray] * w * (2.0f * fmaxf(a.fwd.n_dot_d[q], 0.0f));
           }
 #pragma unroll
-          for (int c = 0; c < 3; ++c) G[c] += gd * dir[c];
+          for (int c = 0; c < 3; ++c) G3[c] += gd * dir[c];
           const float nraw[3] = {hd.x, hd.y, hd.z};
           const float len = fmaxf(sqrtf(nraw[0] * nraw[0] + nraw[1] * nraw[1] + nraw[2] * nraw[2]), 1e-12f);
           const float v[3] = {-(nraw[0] / len), -(nraw[1] / len), -(nraw[2] / len)};
           float gv[3], gu[3], gn[3];
-          normalize_bwd(v, G, gv);
+          normalize_bwd(v, G3, gv);
           gu[0] = -gv[0]; gu[1] = -gv[1]; gu[2] = -gv[2];
           normalize_bwd(nraw, gu, gn);
           qh.y = gn[0]; qh.z = gn[1]; qh.w = gn[2];
@@ -662,59 +689,57 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
         }
       }
       if (valid && a.gout.dz_heads) *reinterpret_cast<float4*>(a.gout.dz_heads + q * 16 + 4 * g) = qh;
-      {
-        const float v[8] = {qh.x, qh.y, qh.z, qh.w, 0.0f, 0.0f, 0.0f, 0.0f};
-        split8(v, XH);
-      }
     }
 
-    // ---------------- stage 1: d hidden = W_rgb^T dz (pf groups), masked by the mid hidden layer's ReLU; the d a_mid rows leave ---
+    // ---------------- stage 1: d hidden = W_rgb^T dz (before the mid hidden layer's ReLU mask: applied where it is consumed) -------
+    f32x4 G8[8];
+    unsigned bmh[2];
     {
       const AsyncD db = asyncd(a.saved.relu_bits, ((long long)L * n_max + p0) * 32, rows, 32);
       u32x2t b0 = ald8(db, vrow * 32 + 8 * g);
       r.since = 0;
-      X3 XR[2];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) XR[0][q] = X0[q];
-      split8(z8, XR[1]);
-      f32x4 acc[8];
-      gemm_x6<8, 2, 2, GI_ZERO>(acc, XR, r, Wf, smem, NoHook());
+      gemm_j<8, 2, GI_ZERO>(G8, [&](int kk, int i, float& x, float& y) {  // K-step 0 slot (g = 1, e = 0..2) = dz; K-step 1 zero
+        x = (kk == 0 && g == 1) ? (i == 0 ? dz[0] : (i == 1 ? dz[2] : 0.0f)) : 0.0f;
+        y = (kk == 0 && g == 1 && i == 0) ? dz[1] : 0.0f;
+      }, NoNote(), r, Wf, smem, NoHook());
       wait_loads(r);
       tie1(b0);
-      const unsigned bm[2] = {b0.x, 0u};
-      epi_masked<true, 4>(acc, X, bm, rowd(a.gout.da_mid, (long long)p0 * 512, rows, 512), vrow * 512 + 32 * g, r);  // X[0..3] = d a_mid
+      bmh[0] = b0.x; bmh[1] = 0u;
     }
-    // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid; its rows leave -----------------
+    // ---------------- stage 2: d bottleneck = W_mid[:, 34:]^T d a_mid (the d a_mid rows leave here) -----------------
+    f32x4 Gb[16];
     {
-      f32x4 acc[16];
-      gemm_x6<16, 4, 8, GI_ZERO>(acc, X, r, Wf, smem, NoHook());
-      epi_rows<false, 8>(acc, X, rowd(a.gout.d_bott, (long long)p0 * 1024, rows, 1024), vrow * 1024 + 32 * g, r);  // X = d bottleneck
+      const RowD d_damid = rowd(a.gout.da_mid, (long long)p0 * 512, rows, 512);
+      const SrcMasked<8> sm{G8, bmh};
+      gemm_j<16, 4, GI_ZERO>(Gb, sm, NoNote(), r, Wf, smem, [&](int gi) { hook_rows<48, 4>(gi, d_damid, vrow * 512 + 32 * g, sm, r); });
     }
-    // ---------------- stage 3: d emb = [W_b; W_heads]^T [d b; dz_heads], masked by the embedding's ReLU: dy[L-1] -----------------
+    // ---------------- stage 3: d emb = [W_b; W_heads]^T [d b; dz_heads] (the d bottleneck rows leave here) -----------------
+    f32x4 G[16];      // the gradient entering a layer's output BEFORE that layer's ReLU mask bm
+    unsigned bm[2];
     {
       const AsyncD db = asyncd(a.saved.relu_bits, ((long long)(L - 1) * n_max + p0) * 32, rows, 32);
       u32x2t b0 = ald8(db, vrow * 32 + 8 * g);
       r.since = 0;
-      X3 X9[9];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) X9[kk][q] = X[kk][q];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) X9[8][q] = XH[q];
-      f32x4 acc[16];
-      gemm_x6<16, 9, 9, GI_ZERO>(acc, X9, r, Wf, smem, NoHook());
+      const RowD d_dbott = rowd(a.gout.d_bott, (long long)p0 * 1024, rows, 1024);
+      const SrcAcc<false, 16> sb{Gb};
+      gemm_j<16, 9, GI_ZERO>(G, [&](int kk, int i, float& x, float& y) {  // ninth K-step: slot (g, e < 4) = heads row 4 g + e
+        if (kk < 8) {
+          sb(kk, i, x, y);
+        } else {
+          x = i == 0 ? qh.x : (i == 1 ? qh.z : 0.0f);
+          y = i == 0 ? qh.y : (i == 1 ? qh.w : 0.0f);
+        }
+      }, NoNote(), r, Wf, smem, [&](int gi) { hook_rows<48, 8>(gi, d_dbott, vrow * 1024 + 32 * g, sb, r); });
       wait_loads(r);
       tie1(b0);
-      const unsigned bm[2] = {b0.x, b0.y};
-      epi_masked<true, 8>(acc, X, bm, d_dy(L - 1), vrow * 1024 + 32 * g, r);  // X = dy[L-1]
+      bm[0] = b0.x; bm[1] = b0.y;
     }
-    // ---------------- stage 4: trunk, layers L-1 .. 1 -----------------
+    // ---------------- stage 4: trunk, layers L-1 .. 1: dy[l] = G masked by bm; its rows leave from the GEMM that reads it ----------
     float part[3] = {0.0f, 0.0f, 0.0f}, rawu[3] = {0.0f, 0.0f, 0.0f};
     float fq[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) fq[t] = P.freqs[4 * g + t];
-    auto enc_part = [&]() {  // (encoded-input part)^T x dy, folded into the variance gradient with the saved features
+    auto enc_part = [&](int l_rows) {  // (encoded-input part)^T x dy, folded into the variance gradient with the saved features
       const AsyncD d_enc = asyncd(a.saved.enc, (long long)p0 * 512, rows, 512);
       u32x4t fr[8];
       fr[0] = aldq<0>(d_enc, vrow * 512 + 32 * g);   fr[1] = aldq<16>(d_enc, vrow * 512 + 32 * g);
@@ -723,7 +748,13 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
       fr[6] = aldq<384>(d_enc, vrow * 512 + 32 * g); fr[7] = aldq<400>(d_enc, vrow * 512 + 32 * g);
       r.since = 0;
       f32x4 eacc[8];
-      gemm_x6<8, 8, 8, GI_ZERO>(eacc, X, r, Wf, smem, NoHook());
+      const SrcMasked<16> sm{G, bm};
+      if (l_rows >= 0) {
+        const RowD dd = d_dy(l_rows);
+        gemm_j<8, 8, GI_ZERO>(eacc, sm, NoNote(), r, Wf, smem, [&](int gi) { hook_rows<24, 8>(gi, dd, vrow * 1024 + 32 * g, sm, r); });
+      } else {
+        gemm_j<8, 8, GI_ZERO>(eacc, sm, NoNote(), r, Wf, smem, NoHook());
+      }
       wait_loads(r);
       tie8(fr);
       float ft[24];
@@ -733,19 +764,21 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
     };
 #pragma unroll 1
     for (int l = L - 1; l >= 1; --l) {
-      if (INPUT && l == P.skip_layer) enc_part();
+      if (INPUT && l == P.skip_layer) enc_part(-1);
       const AsyncD db = asyncd(a.saved.relu_bits, ((long long)(l - 1) * n_max + p0) * 32, rows, 32);
       u32x2t b0 = ald8(db, vrow * 32 + 8 * g);
       r.since = 0;
+      const RowD dd = d_dy(l);
       f32x4 acc[16];
-      gemm_x6<16, 8, 8, GI_ZERO>(acc, X, r, Wf, smem, NoHook());
+      const SrcMasked<16> sm{G, bm};
+      gemm_j<16, 8, GI_ZERO>(acc, sm, NoNote(), r, Wf, smem, [&](int gi) { hook_rows<48, 8>(gi, dd, vrow * 1024 + 32 * g, sm, r); });
       wait_loads(r);
       tie1(b0);
-      const unsigned bm[2] = {b0.x, b0.y};
-      epi_masked<true, 8>(acc, X, bm, d_dy(l - 1), vrow * 1024 + 32 * g, r);  // X = dy[l-1]; its rows leave
+      bm[0] = b0.x; bm[1] = b0.y;
+      copy_acc(G, acc);
     }
     if (INPUT) {
-      enc_part();
+      enc_part(0);  // keeps dy[0]
       // ---------------- stage 5: gradient w.r.t. the Gaussian's variance -> pixel_area / sqradius -----------------
       float dvar[3];
 #pragma unroll
@@ -776,6 +809,11 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
         }
         a.gout.d_input[q] = gg;
       }
+    } else {  // dy[0] has no GEMM behind it on this path: its rows leave here
+      const RowD dd = d_dy(0);
+      const SrcMasked<16> sm{G, bm};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) store_kstep(dd, vrow * 1024 + 32 * g, kk, sm, r);
     }
   }
   ring_finish(r, wid);

@@ -98,12 +98,14 @@ __device__ __forceinline__ void sh34_attenuated(float x, float y, float z, float
   sh[33] = 0.72892666017482986f * (x2 * re7 - y2 * im7) * e8;
 }
 
-// ReLU as ONE v_max_f32.  Written as (non-volatile) asm: from fmaxf / fmed3 hipcc emits v_max(x, x) first (it
-// canonicalises a possible sNaN), two VALU per value in every layer epilogue.  NaN -> 0, as before.
+// ReLU as ONE instruction: v_max_i32 on the bits (as signed integers every negative float, and -0, is negative; positive floats
+// keep their order) -- from fmaxf / fmed3 hipcc emits v_max(x, x) first (it canonicalises a possible sNaN), two VALU per value in
+// every layer epilogue.  Deliberately NOT inline asm (rounds 1-3 had `asm("v_max_f32 %0, 0, %1")`): the compiler's hazard
+// recogniser does not see an asm operand, and a ReLU placed right behind the MFMA that writes its input reads the register
+// before the matrix pipe has written it (found in rsn_field_x6_train.hip, round 4).  -NaN -> 0, +NaN stays.
 __device__ __forceinline__ float relu_f(float x) {
-  float y;
-  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-  return y;
+  const int xi = __float_as_int(x);
+  return __int_as_float(xi > 0 ? xi : 0);
 }
 
 // Rows kept for the backward pass / the weight gradients.  fp32 rows in the exact and the split-bf16 modes; in the
@@ -168,17 +170,19 @@ template <bool SBF>
 __device__ __forceinline__ void sv_put(const RowBuf& b, int nb, int q, int, const float4 v) {
   if (SBF) {
     const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), b.r, b.voff, (nb * 4 + q) * 16, RSN_SAVED_ROW_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), b.r, b.voff + (unsigned)((nb * 4 + q) * 16), 0, RSN_SAVED_ROW_AUX);
   } else {
     const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (nb * 4 + q) * 32, RSN_SAVED_ROW_AUX);
+    // (offset in the vector offset / immediate, scalar offset 0: a > 8-byte buffer store with a REGISTER soffset is not protected
+    // by hipcc against a VALU overwriting its data registers in the next instruction -- see st16, rsn_ringt.h)
+    __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff + (unsigned)((nb * 4 + q) * 32), 0, RSN_SAVED_ROW_AUX);
   }
 }
 // the float4 of K-iteration `it` of the lane's row (features it*8 + 4h ..): the same bytes sv_put(nb = it/4, q = it%4) writes
 __device__ __forceinline__ void sv_put_it(const float*, int, const float4) {}
 __device__ __forceinline__ void sv_put_it(const RowBuf& b, int it, const float4 v) {
   const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-  if ((unsigned)it * 32u < b.lim) __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff, (unsigned)it * 32u, RSN_SAVED_ROW_AUX);  // wave-uniform
+  if ((unsigned)it * 32u < b.lim) __builtin_amdgcn_raw_buffer_store_b128(o, b.r, b.voff + (unsigned)it * 32u, 0, RSN_SAVED_ROW_AUX);  // wave-uniform
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,23 +512,56 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NBO]) {
 // packed into NBO/2 words (rsn_field_saved.relu_bits).  The dX sweeps mask by these bits instead of re-reading the
 // saved fp32 activations (1 KiB per point and layer -> 32 B; 124 fewer live registers in the sweeps).
 __device__ __forceinline__ unsigned relu_bits16(const f32x16& a) {
-  // pre-activation x > 0  <=>  its bit pattern, as an int, > 0: v_med3_i32(t, 0, 1), then v_lshl_or_b32.  Written as
-  // (non-volatile) asm: hipcc turns the C form into v_cmp_lt_i32 (SGPR pair) + a hazard nop + v_cndmask + v_or3.
+  // pre-activation x > 0  <=>  the bits of relu(x) (relu_f: one v_max_i32, shared with the ReLU epilogue beside this) are non-zero:
+  // v_min_u32(., 1), then v_lshl_or_b32.  The C forms (`t > 0`, clamp(t, 0, 1)) become v_cmp_lt_i32 (SGPR pair) + a hazard nop +
+  // v_cndmask + v_or3.  The asm takes the relu'd value, NOT the accumulator: an asm operand that is an MFMA result is invisible to
+  // the compiler's hazard recogniser (see relu_f); behind the compiler's own v_max_i32 it is an ordinary VALU result.
   unsigned b = 0u;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int t = (int)__float_as_uint(a[r]);
-    int bit;
+    const unsigned lo = __float_as_uint(relu_f(a[r]));
+    unsigned bit;
     if (r == 0) {
-      asm("v_med3_i32 %0, %1, 0, 1" : "=v"(bit) : "v"(t));
-      b = (unsigned)bit;
+      asm("v_min_u32 %0, %1, 1" : "=v"(bit) : "v"(lo));
+      b = bit;
     } else {
       unsigned nb;
-      asm("v_med3_i32 %0, %2, 0, 1\n\tv_lshl_or_b32 %1, %0, %3, %4" : "=&v"(bit), "=v"(nb) : "v"(t), "n"(r), "v"(b));
+      asm("v_min_u32 %0, %2, 1\n\tv_lshl_or_b32 %1, %0, %3, %4" : "=&v"(bit), "=v"(nb) : "v"(lo), "n"(r), "v"(b));
       b = nb;
     }
   }
   return b;
+}
+
+// the same for four relu'd values at bit positions 4 q .. 4 q + 3 (the ReLU epilogues below take the bits from the values they
+// have just formed: no second v_max per value)
+template <int Q>
+__device__ __forceinline__ unsigned relu_bits4q(unsigned b, const float4 v) {
+  const unsigned lo[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    unsigned bit, nb;
+    if (Q == 0 && t == 0) {
+      asm("v_min_u32 %0, %1, 1" : "=v"(bit) : "v"(lo[t]));
+      b = bit;
+    } else if (t == 0) {
+      asm("v_min_u32 %0, %2, 1\n\tv_lshl_or_b32 %1, %0, %3, %4" : "=&v"(bit), "=v"(nb) : "v"(lo[t]), "n"(4 * Q), "v"(b));
+      b = nb;
+    } else if (t == 1) {
+      asm("v_min_u32 %0, %2, 1\n\tv_lshl_or_b32 %1, %0, %3, %4" : "=&v"(bit), "=v"(nb) : "v"(lo[t]), "n"(4 * Q + 1), "v"(b));
+      b = nb;
+    } else if (t == 2) {
+      asm("v_min_u32 %0, %2, 1\n\tv_lshl_or_b32 %1, %0, %3, %4" : "=&v"(bit), "=v"(nb) : "v"(lo[t]), "n"(4 * Q + 2), "v"(b));
+      b = nb;
+    } else {
+      asm("v_min_u32 %0, %2, 1\n\tv_lshl_or_b32 %1, %0, %3, %4" : "=&v"(bit), "=v"(nb) : "v"(lo[t]), "n"(4 * Q + 3), "v"(b));
+      b = nb;
+    }
+  }
+  return b;
+}
+__device__ __forceinline__ unsigned relu_bits4(unsigned b, const float4 v, int q) {  // q: a constant after unrolling
+  return q == 0 ? relu_bits4q<0>(b, v) : (q == 1 ? relu_bits4q<1>(b, v) : (q == 2 ? relu_bits4q<2>(b, v) : relu_bits4q<3>(b, v)));
 }
 
 template <int NBO>
@@ -605,10 +642,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
   unsigned bw[NBS / 2 > 0 ? NBS / 2 : 1];
 #pragma unroll
   for (int nb = 0; nb < NBS; ++nb) {
-    if (RELU && bits) {  // the block's 16 mask bits, taken while its accumulators are being read anyway
-      const unsigned b16 = relu_bits16(acc[nb]);
-      if (nb & 1) bw[nb / 2] |= b16 << 16; else bw[nb / 2] = b16;
-    }
+    unsigned b16 = 0u;  // the block's 16 mask bits, taken from the relu'd values as they are formed (dead code without `bits`)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
@@ -617,9 +651,13 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
         v.y = relu_f(v.y);
         v.z = relu_f(v.z);
         v.w = relu_f(v.w);
+        b16 = relu_bits4(b16, v, q);
       }
       xl[(nb * 4 + q) * 64] = v;
       if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
+    }
+    if (RELU) {
+      if (nb & 1) bw[nb / 2] |= b16 << 16; else bw[nb / 2] = b16;
     }
   }
   if (RELU && bits) {
@@ -642,10 +680,7 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, S
   unsigned bw[NBO / 2 > 0 ? NBO / 2 : 1];
 #pragma unroll
   for (int nb = 0; nb < NBO; ++nb) {
-    if (RELU && bits) {
-      const unsigned b16 = relu_bits16(acc[nb]);
-      if (nb & 1) bw[nb / 2] |= b16 << 16; else bw[nb / 2] = b16;
-    }
+    unsigned b16 = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
@@ -654,6 +689,7 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, S
         v.y = relu_f(v.y);
         v.z = relu_f(v.z);
         v.w = relu_f(v.w);
+        b16 = relu_bits4(b16, v, q);
       }
       xl[(nb * 4 + q) * 64] = v;
       if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
@@ -662,6 +698,9 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, S
       acc[nb][4 * q + 1] = bv.y;
       acc[nb][4 * q + 2] = bv.z;
       acc[nb][4 * q + 3] = bv.w;
+    }
+    if (RELU) {
+      if (nb & 1) bw[nb / 2] |= b16 << 16; else bw[nb / 2] = b16;
     }
   }
   if (RELU && bits) {

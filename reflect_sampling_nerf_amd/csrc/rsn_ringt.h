@@ -137,7 +137,11 @@ __device__ __forceinline__ RowD rowd(const void* base, long long byte_off, int r
 template <class RING>
 __device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff, const bf16x8 v, RING& r) {
 #ifndef RSN_RT_NO_STORES
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, v), d.r, voff, soff, RT_STORE_AUX);
+  // (offset through the VECTOR offset / the instruction's immediate, scalar offset 0.  With a register soffset hipcc's hazard
+  // recogniser lets a VALU overwrite the data registers of a > 8-byte buffer store in the very next instruction -- LLVM's
+  // createsVALUHazard: "only if not using a register in the soffset field" -- and on gfx950 that store then carries the NEW value
+  // in the last quarter of every 16 lanes: found in rsn_field_x6_train.hip, round 4, where a mask temporary followed the store)
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, v), d.r, voff + soff, 0, RT_STORE_AUX);
 #ifndef RSN_RT_UNCOUNTED
   r.c0 += 1;
   r.since += 1;
@@ -148,7 +152,7 @@ template <class RING>
 __device__ __forceinline__ void st8(const RowD& d, unsigned voff, unsigned soff, unsigned w0, unsigned w1, RING& r) {
 #ifndef RSN_RT_NO_STORES
   const u32x2t v = {w0, w1};
-  __builtin_amdgcn_raw_buffer_store_b64(v, d.r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(v, d.r, voff + soff, 0, 0);
 #ifndef RSN_RT_UNCOUNTED
   r.c0 += 1;
   r.since += 1;

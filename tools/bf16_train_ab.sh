@@ -1,10 +1,10 @@
 #!/bin/bash
 # The plain-bf16 training step with the product library against variant builds (extra -D macros; built HERE beforehand with
 # `python -c "from tools._variant import build_variant; print(build_variant([...]))"`), on one box.
-# Usage: tools/bf16_train_ab.sh <tag> <variant .so> [<variant .so> ...]
+# Usage: [RSN_AB_MMA=bf16x6] tools/bf16_train_ab.sh <tag> <variant .so> [<variant .so> ...]
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-B="python bench.py --mma bf16 --no-secondary --no-cpu-baseline --steps 10 --warmup 3"
+B="python bench.py --mma ${RSN_AB_MMA:-bf16} --no-secondary --no-cpu-baseline --steps 10 --warmup 3"
 timeout -k 10 300 $B > $OUT/base.json 2> $OUT/base.err || exit 1
 i=0
 for lib in "$@"; do

@@ -21,7 +21,9 @@
 void rsn_set_error(const char*, ...) {}
 
 #define LAYERS 63             // 256 x 256 layers per tile-pass (the stream wraps around a 7-layer block)
+#ifndef STREAM_GROUPS
 #define STREAM_GROUPS (7 * 8)  // 7 layers x 128 fragments = 56 groups of 16 KiB: 0.9 MB, L2-resident like the product's 1.3 MB
+#endif
 
 template <int variant>
 __global__ __launch_bounds__(512, 2) void probe_kernel(const float* __restrict__ stream, float* __restrict__ out, int passes) {
