@@ -129,7 +129,9 @@ const char* rsn_last_error(void);
  * MMA mode (ABI 15).  Default (rsn_field_kernel): enc = fp32 [N,104], sh = fp32 [N,40] in that kernel's slot order.  With
  * mma_mode == RSN_MMA_BF16 at width 256 the training forward / backward run on the LDS weight ring
  * (rsn_field_bf16_train.hip): enc = bf16 [N,128], sh = bf16 [N,64], slot s = 32 kk + 8 g + e of lane group g, and the
- * ReLU bit words of rsn_field_saved.relu_bits are laid out [L+1][N][4 lane groups][2 words].
+ * ReLU bit words of rsn_field_saved.relu_bits are laid out [L+1][N][4 lane groups][2 words].  mma_mode == RSN_MMA_BF16X6 at
+ * width 256 (rsn_field_x6_train.hip, the split-bf16 = fp32-equivalent mode on the same ring): the same slot order and bit
+ * layout, enc / sh rows in fp32 (narrow_bf16 = 0); every wide buffer stays fp32 [N,W] in natural feature order.
  * Outputs: *enc_cols / *sh_cols = row length in elements, *narrow_bf16 = 1 if enc / sh rows hold bf16; enc_map[s] / sh_map[s]
  * (caller arrays of 128 / 64 ints, HOST) = column of the reference's 99-wide NeRFEncoding output / 34-wide SH encoding
  * (nerfstudio N2; reflect_sampling_nerf_components.py:38-140) that slot s carries, -1 for padding: the col_map of the

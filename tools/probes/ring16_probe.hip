@@ -7,6 +7,8 @@
 // LDS footprint (141 KiB: one workgroup per CU, two waves per SIMD), and nothing else:
 //   A  pure MFMA: the same accumulator / operand registers, no ring, no LDS read          (the matrix pipe's own rate here)
 //   B  the ring GEMM loop alone: 256 x 256 layers back to back, the same X operands re-used (no epilogue)
+//   C  the split-bf16 (bf16x6) loop of rsn_field_x6_train.hip: three 1 KiB pieces per fragment, 1 / 2 / 3 MFMAs per piece, one 16-point
+//      half per wave (-DSTREAM_GROUPS=n: stream length in 16 KiB groups; 432 = the 7 MB of the split-bf16 forward + transposed stream)
 // Output: TFLOP/s of A and B and B / 2500: B is the roofline of the kernel's GEMM structure on this box -- what the product kernel
 // would reach with free layer hand-offs, encode, heads, SH and stores.  (Measured, profiles/r04_ring16_probe.txt: A 2,262 TFLOP/s
 // = 0.90 of the dense peak, B 1,961 TFLOP/s = 0.78; the product kernel's 1,313 TFLOP/s is 67 % of B: the loop is NOT what holds
