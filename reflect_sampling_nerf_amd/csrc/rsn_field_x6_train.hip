@@ -26,11 +26,16 @@
 // ReLU bit words [L+1][N][4 lane groups][2 words], wide buffers fp32 [N,W] in natural feature order.
 #include "rsn_ringt.h"
 
+// Ring groups in flight ahead of the one being consumed.  The split-bf16 stream is 3.9 MB forward + 3.0 MB transposed -- beyond an
+// XCD's 4 MiB L2 -- so a deeper ring pays in the backward where the plain-bf16 kernels saw nothing: 3 / 5 / 7 groups ahead: 7.53 /
+// 6.94 / 7.10 ms per step (the input-gradient launch 2.12 -> 1.61 ms).  The forward has no LDS for more than 3 beside its stashes; with
+// the stash cut to 6 KiB per wave (raw-coordinate K-step rebuilt from registers) 4 groups ahead measured the same as 3
+// (profiles/r04_x6_ab.txt).
 #ifndef X6_LEAD_FWD
 #define X6_LEAD_FWD 3
 #endif
 #ifndef X6_LEAD_BWD
-#define X6_LEAD_BWD 3
+#define X6_LEAD_BWD 5
 #endif
 #define X6_STASH_BYTES (8 * 1024)   // per wave: 8 float4 per lane -- the encoded inputs [kk (4)][half (2)], later the SH inputs / the
                                     // derivative factors of the encoding
