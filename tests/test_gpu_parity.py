@@ -1905,6 +1905,46 @@ def test_reducer_on_rccl_single_rank(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("need_input", [False, True])
+def test_plain_bf16_ring_sweeps_repeat_bitwise(dev, need_input):
+    """The plain-bf16 ring training kernels (rsn_field_bf16_train.hip): forward + backward sweep of one level four times on the same
+    inputs, every saved row and every gradient row bit for bit (no atomics in these kernels: any difference is a hazard -- see the
+    split-bf16 test below for the one round 4 found)."""
+    from oracle import cpu_ref
+    from reflect_sampling_nerf_amd import train_graph
+
+    torch.manual_seed(0)
+    R, S = 37, 32
+    cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S, num_importance_samples=S, num_reflect_coarse_samples=16,
+                                            num_reflect_importance_samples=16)
+    model = cfg.setup(scene_box=None, num_train_data=1)
+    with torch.no_grad():
+        model.field.field_output_density.net.bias += 2.0
+    model.to(dev).train()
+    f = model.field
+    f.set_mma_mode("bf16")
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=1)
+    o, d, pa = o.to(dev), d.to(dev), pa.to(dev).reshape(-1)
+    bins = (2.0 + 4.0 * torch.linspace(0, 1, S + 1)).repeat(R, 1).to(dev).contiguous()
+    gen = torch.Generator().manual_seed(3)
+    gin = {"sigma": torch.randn(R, S, generator=gen).to(dev), "color": torch.randn(R, S, 3, generator=gen).to(dev),
+           "pred_normals": torch.randn(R, S, 3, generator=gen).to(dev), "n_dot_d": torch.randn(R, S, generator=gen).to(dev),
+           "roughness": torch.randn(R, S, generator=gen).to(dev)}
+    first = None
+    for _ in range(4):
+        lv = f.evaluate_frustums_train(o, d, pa, bins, want_normals=not need_input)
+        go = train_graph._field_backward(f, (o, d, pa), bins, lv, gin, need_input)
+        torch.cuda.synchronize()
+        cur = {**{"saved." + k: v for k, v in lv["saved"].items()}, **{"gout." + k: v for k, v in go.items()},
+               **{k: lv[k] for k in ("sigma", "color", "pred_normals", "diff", "tint", "roughness")}}
+        if first is None:
+            first = {k: v.clone() for k, v in cur.items()}
+        else:
+            for k, v in cur.items():
+                assert torch.equal(v.view(torch.uint8), first[k].view(torch.uint8)), f"not repeatable: {k}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("need_input", [False, True])
 def test_split_bf16_ring_rows_match_the_exact_kernels_and_repeat_bitwise(dev, need_input):
     """The split-bf16 (bf16x6) training kernels on the LDS weight ring (rsn_field_x6_train.hip) against the exact-fp32 kernels, buffer
     by buffer on the same inputs: every saved forward row and every layer-gradient row of the backward sweep (the operands of the
