@@ -30,7 +30,7 @@ _MFMA_VGPR = ("-mllvm", "-amdgpu-mfma-vgpr-form")
 # for the activations); hipcc prices them above its default 16 K budget, unrolls them late and partially, and the activation /
 # accumulator arrays then live in scratch (832 B per lane).  With the budget raised: no scratch in the backward kernels.
 _UNROLL_BUDGET = ("-mllvm", "-pragma-unroll-threshold=131072")
-SOURCE_FLAGS = {"rsn_field.hip": _MFMA_VGPR, "rsn_field_bwd.hip": _MFMA_VGPR, "rsn_field_x6_train.hip": _UNROLL_BUDGET}
+SOURCE_FLAGS = {"rsn_field.hip": _MFMA_VGPR, "rsn_field_bwd.hip": _MFMA_VGPR, "rsn_field_x6_train.hip": _UNROLL_BUDGET, "rsn_field_f32_ring.hip": _UNROLL_BUDGET}
 
 
 def _headers():

@@ -18,7 +18,8 @@
     defined(RSN_R16_NO_MFMA) || defined(RSN_R16_DOUBLE_MFMA) || defined(RSN_PHASE_TIMERS) || \
     defined(RSN_DIAG_NO_SAVED_ROWS) || defined(RSN_DIAG_WG_NO_FLUSH) || defined(RSN_DIAG_X6_SAMEW) || \
     defined(RSN_RT_NO_STORES) || defined(RSN_RT_UNCOUNTED) || defined(RSN_RT_NO_LOADS) || defined(RSN_RT_NO_BITS) || \
-    defined(RSN_RT_NO_SWEEP) || defined(RSN_RT_NO_PREP) || defined(RSN_RT_SOFFSET_STORES)
+    defined(RSN_RT_NO_SWEEP) || defined(RSN_RT_NO_PREP) || defined(RSN_RT_SOFFSET_STORES) || defined(RSN_F32_RING_TRAIN) || defined(RSN_F32_NO_WAIT) || \
+    defined(RSN_F32_NO_BARRIER)
 #error "timing-diagnostic macros need -DRSN_DIAG_BUILD (tools/_variant.py): they never go into librsn_hip.so"
 #endif
 #endif
@@ -101,6 +102,14 @@ struct RsnPackedLayout {
   // RSN_MMA_BF16X6 at width 256 (rsn_field_x6_train.hip): the same stream with every fragment as THREE 1 KiB pieces -- the lo, mid
   // and hi bf16 parts of the fp32 weights, in that order (small products first); q_pf = 3 and every group count above is x 3
   int q_pf;                           // 1 KiB pieces per fragment of q_stream: 1 (plain bf16) or 3 (split-bf16)
+  // RSN_MMA_F32 at width 256 (tools/probes/rsn_field_f32_ring.hip, the exact-fp32 training forward on the LDS weight ring: diagnostic builds only): the fp32 fragments
+  // ([lane][4] = 1 KiB, the (it, nb) chunks of the segments above) as ONE linear stream in consumption order, every GEMM padded to
+  // whole groups of 16 fragments: enc0 (13 its x 8 blocks, padded to 14), then per layer l = 1..L-1 the x part (32 x 8) and, behind
+  // l == skip, the encoded-input part; [bottleneck; heads] 32 x 9; mlp_mid SH part 5 (padded to 8) x 4; its x part 32 x 4; RGB head
+  // 16 x 1.  Directly behind it the TRANSPOSED trunk of the analytic-normal sweep: for l = L-1..1 the (encoded-input part of the skip
+  // layer)^T 32 x 4 in front of l == skip and (x part of layer l)^T 32 x 8; last (layer 0)^T 32 x 4.
+  size_t f_stream;                    // 0 = absent
+  int f_groups, ft_end;               // forward stream = groups [0, f_groups), transposed trunk = [f_groups, ft_end)
   size_t total;                       // floats
 };
 #ifndef RSN_RING_GROUP_FRAGS
@@ -112,6 +121,18 @@ struct RsnPackedLayout {
 inline bool rsn_ring_training(const rsn_field_desc* d) {
   return (d->mma_mode == RSN_MMA_BF16 || d->mma_mode == RSN_MMA_BF16X6) && d->width == 256 &&
          d->num_layers <= RSN_RING_MAX_LAYERS && RSN_RING_GROUP_FRAGS == 16;
+}
+
+// The exact-fp32 TRAINING FORWARD on the LDS weight ring (tools/probes/rsn_field_f32_ring.hip): built in round 4, bit-identical to
+// rsn_field_kernel<8, true, 0> and 7 % slower -- NOT part of the product: only diagnostic builds with
+// -DRSN_F32_RING_TRAIN (tools/_variant.py, extra source) pack its stream and dispatch to it.
+inline bool rsn_f32_ring_training(const rsn_field_desc* d) {
+#ifdef RSN_F32_RING_TRAIN
+  return d->mma_mode == RSN_MMA_F32 && d->width == 256 && d->num_layers <= RSN_RING_MAX_LAYERS && RSN_RING_GROUP_FRAGS == 16;
+#else
+  (void)d;
+  return false;
+#endif
 }
 
 int rsn_compute_layout(const rsn_field_desc* desc, RsnPackedLayout* L);

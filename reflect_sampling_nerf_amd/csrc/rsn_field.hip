@@ -77,6 +77,13 @@ static int launch_field_jobs(const rsn_field_desc* d, FieldArgs* js, int n, void
     for (int k = 0; k < J.n_jobs; ++k) tn += ((long long)J.j[k].n_rays * J.j[k].S + tp - 1) / tp;
     return mode == RSN_MMA_BF16X6 ? rsn_launch_field_x6_train(tn, st, J) : rsn_launch_field_bf16_train(tn, st, J);
   }
+#ifdef RSN_F32_RING_TRAIN  // (diagnostic builds only: the ring form of the exact-fp32 training forward)
+  if (train && rsn_f32_ring_training(d)) {  // 128-point tiles
+    long long tn = 0;
+    for (int k = 0; k < J.n_jobs; ++k) tn += ((long long)J.j[k].n_rays * J.j[k].S + 127) / 128;
+    return rsn_launch_field_f32_train(tn, st, J);
+  }
+#endif
   if (mode == RSN_MMA_BF16X6 || (!train && mode == RSN_MMA_BF16X3)) {  // split-bf16 instantiations: rsn_field_split.hip
     rc = rsn_launch_field_split(d->width, train, mode == RSN_MMA_BF16X6 ? 1 : 2, grid, st, J);
     if (rc != RSN_OK) return rc;

@@ -106,3 +106,5 @@ int rsn_launch_field_bf16_bwd(long long n_tiles256, hipStream_t st, const BwdJob
 // rsn_field_x6_train.hip: the split-bf16 (fp32-equivalent) training kernels on the LDS weight ring (width 256; 128-point tiles)
 int rsn_launch_field_x6_train(long long n_tiles128, hipStream_t st, const FieldJobs& J);
 int rsn_launch_field_x6_bwd(long long n_tiles128, hipStream_t st, const BwdJobs& J);
+// tools/probes/rsn_field_f32_ring.hip (diagnostic builds with -DRSN_F32_RING_TRAIN): the exact-fp32 training forward on the LDS ring
+int rsn_launch_field_f32_train(long long n_tiles128, hipStream_t st, const FieldJobs& J);

@@ -198,6 +198,13 @@ int rsn_compute_layout(const rsn_field_desc* d, RsnPackedLayout* L) {
     L->t_g_end = tg;
     off += (size_t)(tg - L->q_groups) * 16 * blk;
   }
+  if (rsn_f32_ring_training(d)) {
+    const int enc_g = (RSN_ENC_ITS * 8 + 15) / 16, skip = d->skip_layer >= 1 ? 1 : 0;   // 104 fragments -> 7 groups
+    L->f_groups = enc_g * (1 + skip) + (d->num_layers - 1) * 16 + 18 + 2 + 8 + 1;
+    L->ft_end = L->f_groups + (d->num_layers - 1) * 16 + 8 * (1 + skip);
+    L->f_stream = off;
+    off += (size_t)L->ft_end * 16 * blk;
+  }
   L->total = off;
   return RSN_OK;
 }
@@ -384,10 +391,10 @@ __global__ void rsn_pack_split_all_kernel(const SplitJob job) {
 }
 
 // ---- ring stream (RSN_MMA_BF16, width 256): split-0 fragments of the h_* segments re-ordered into consumption order
-#define RING_MAX_PIECES 40
+#define RING_MAX_PIECES 48
 struct RingPiece {
-  unsigned src;      // float offset of the split-bf16 source segment ([k16][nbo_src][3][lane][8 bf16])
-  short nbo_src, nb0, nbo, ks_real, ks;
+  unsigned src;      // float offset of the source segment: split-bf16 ([k16][nbo_src][3][lane][8 bf16], mul = 3) or fp32 ([it][nbo_src][lane][4], mul = 1)
+  short nbo_src, nb0, nbo, ks_real, ks, mul;
   int frag0;         // first fragment of this piece in the stream
 };
 struct RingJob {
@@ -406,7 +413,7 @@ __global__ void rsn_pack_ring_kernel(const RingJob job) {  // one 64-thread work
   const int kk = i / pc.nbo, nb = pc.nb0 + i % pc.nbo;
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   if (kk < pc.ks_real)
-    v = reinterpret_cast<const uint4*>(job.packed + pc.src + ((size_t)(kk * pc.nbo_src + nb) * 3) * 256)[threadIdx.x];
+    v = reinterpret_cast<const uint4*>(job.packed + pc.src + ((size_t)(kk * pc.nbo_src + nb) * pc.mul) * 256)[threadIdx.x];
   reinterpret_cast<uint4*>(job.dst + (size_t)f * 256)[threadIdx.x] = v;
 }
 
@@ -471,6 +478,8 @@ struct PackCollector {
   std::vector<SplitSeg> splits;
   bool have_ring = false;
   RingJob ring;
+  bool have_fring = false;
+  RingJob fring;   // the fp32 consumption-order stream (f_stream)
 };
 thread_local PackCollector* g_collect = nullptr;
 
@@ -807,6 +816,47 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
                 frag, L.t_g_end);
   }
 
+  // ---------------- fp32 consumption-order stream (rsn_field_f32_train.hip): copies of the fp32 fragments above ----------------
+  if (L.f_stream != 0) {
+    RingJob rj;
+    memset(&rj, 0, sizeof(rj));
+    rj.packed = packed;
+    rj.dst = packed + L.f_stream;
+    int frag = 0;
+    auto piece = [&](size_t src, int nbo, int its_real, int its) {
+      RingPiece& q = rj.p[rj.n_pieces++];
+      q.src = (unsigned)src; q.nbo_src = (short)nbo; q.nb0 = 0; q.nbo = (short)nbo;
+      q.ks_real = (short)its_real; q.ks = (short)its; q.mul = 1; q.frag0 = frag;
+      frag += its * nbo;
+    };
+    const int enc_its = (RSN_ENC_ITS * 8 + 15) / 16 * 16 / 8;  // 13 -> 14: whole groups
+    piece(L.w_enc0, NB, RSN_ENC_ITS, enc_its);
+    for (int l = 1; l < d->num_layers; ++l) {
+      piece(L.w_x[l], NB, NB * 4, NB * 4);
+      if (l == d->skip_layer) piece(L.w_enc_skip, NB, RSN_ENC_ITS, enc_its);
+    }
+    piece(L.w_bh, NB + 1, NB * 4, NB * 4);
+    piece(L.w_mid_sh, NBM, RSN_SH_ITS, 8);
+    piece(L.w_mid_x, NBM, NB * 4, NB * 4);
+    piece(L.w_rgb, 1, NBM * 4, NBM * 4);
+    RSN_REQUIRE(frag == L.f_groups * 16, RSN_ERR_INVALID_ARGUMENT, "fp32 stream: %d fragments, layout says %d groups", frag, L.f_groups);
+    for (int l = d->num_layers - 1; l >= 1; --l) {
+      if (l == d->skip_layer) piece(L.wT_enc_skip, 4, NB * 4, NB * 4);
+      piece(L.wT_x[l], NB, NB * 4, NB * 4);
+    }
+    piece(L.wT_enc0, 4, NB * 4, NB * 4);
+    RSN_REQUIRE(rj.n_pieces <= RING_MAX_PIECES && frag == L.ft_end * 16, RSN_ERR_INVALID_ARGUMENT,
+                "fp32 stream: %d fragments in %d pieces, layout says %d groups", frag, rj.n_pieces, L.ft_end);
+    rj.n_frags = frag;
+    if (g_collect) {
+      g_collect->have_fring = true;
+      g_collect->fring = rj;
+    } else {
+      hipLaunchKernelGGL(rsn_pack_ring_kernel, dim3((unsigned)frag), dim3(64), 0, st, rj);
+      RSN_HIP(hipGetLastError());
+    }
+  }
+
   // ---------------- split-bf16 copies (RSN_MMA_BF16X6 / X3 / BF16) of every GEMM segment ----------------
   if (d->mma_mode == RSN_MMA_F32) return RSN_OK;  // the exact-fp32 kernels never read them
   if ((rc = split_seg(packed + L.w_enc0, RSN_ENC_ITS, NB, packed + L.h_enc0, st)) != RSN_OK) return rc;
@@ -835,7 +885,7 @@ extern "C" int rsn_pack_weights(const rsn_field_desc* d, const rsn_field_params*
     auto piece = [&](size_t src, int nbo_src, int nb0, int nbo, int ks_real, int ks) {
       RingPiece& q = rj.p[rj.n_pieces++];
       q.src = (unsigned)src; q.nbo_src = (short)nbo_src; q.nb0 = (short)nb0; q.nbo = (short)nbo;
-      q.ks_real = (short)ks_real; q.ks = (short)ks; q.frag0 = frag;
+      q.ks_real = (short)ks_real; q.ks = (short)ks; q.mul = 3; q.frag0 = frag;
       frag += ks * nbo;
     };
     const int G = RSN_RING_GROUP_FRAGS;
@@ -880,6 +930,7 @@ extern "C" int rsn_pack_weights_table(const rsn_field_desc* d, const rsn_field_p
   col.jobs.clear();
   col.splits.clear();
   col.have_ring = false;
+  col.have_fring = false;
   g_collect = &col;
   const int rc = rsn_pack_weights(d, p, packed, packed_bytes, stream);
   g_collect = nullptr;
@@ -921,6 +972,10 @@ extern "C" int rsn_pack_weights_table(const rsn_field_desc* d, const rsn_field_p
   }
   if (col.have_ring) {
     hipLaunchKernelGGL(rsn_pack_ring_kernel, dim3((unsigned)col.ring.n_frags), dim3(64), 0, st, col.ring);
+    RSN_HIP(hipGetLastError());
+  }
+  if (col.have_fring) {  // (behind rsn_pack_all_kernel on the same stream: it copies what that kernel wrote)
+    hipLaunchKernelGGL(rsn_pack_ring_kernel, dim3((unsigned)col.fring.n_frags), dim3(64), 0, st, col.fring);
     RSN_HIP(hipGetLastError());
   }
   return RSN_OK;
