@@ -103,8 +103,12 @@ __device__ __forceinline__ void ringt_sync(RING& r) {
   int n = r.c0 + RT_PPW * (LEAD - 2);
 #pragma unroll
   for (int i = 0; i < LEAD - 2; ++i) n += r.cp[i];
+#ifndef RSN_RT_NO_WAIT      // (RSN_RT_NO_WAIT / _NO_BARRIER: timing ablations, diagnostic builds only; wrong results by construction)
   wait_vm(n);
+#endif
+#ifndef RSN_RT_NO_BARRIER
   asm volatile("s_barrier" ::: "memory");
+#endif
   ringt_issue(r);
 #pragma unroll
   for (int i = LEAD - 3; i > 0; --i) r.cp[i] = r.cp[i - 1];
