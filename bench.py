@@ -441,7 +441,8 @@ def run_level(pkg, args, dev, steps, warmup, dog):
     mult = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}[args.mma]
     peak = FP32_MFMA_PEAK_TFLOPS if args.mma == "f32" else BF16_MFMA_PEAK_TFLOPS
     return {
-        "workload": "%s: %d rays x %d samples, %d-layer %d-wide MLP, %s, fused forward + composite of one sampling level (eval)"
+        "workload": "%s: %d rays x %d samples, %d-layer %d-wide MLP, %s, forward + composite of one sampling level (eval): TWO launches, "
+                    "the field kernel writes the per-sample outputs the reference's dict carries and rsn_composite_kernel (8 us) reads them"
                     % ("BASELINE configs[1]" if (R, S, args.mma) == (4096, 128, "f32") else
                        "BASELINE configs[3]" if (R, S, args.mma) == (16384, 192, "bf16") else "custom size",
                        R, S, args.layers, args.width,
