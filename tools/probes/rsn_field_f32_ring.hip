@@ -303,7 +303,11 @@ __global__ __launch_bounds__(256) void rsn_field_f32_train_kernel(const FieldJob
         o[c] = a.origins[ray * 3 + c];
         vd[c] = a.directions[ray * 3 + c];
       }
+      #ifdef F32_BRANCHY  // (the shared function with its divergent branch: see frustum_to_contracted_sel)
+      frustum_to_contracted(o, vd, a.pixel_area[ray], a.bins[ray * (a.S + 1) + s], a.bins[ray * (a.S + 1) + s + 1], mc, vc);
+#else
       frustum_to_contracted_sel(o, vd, a.pixel_area[ray], a.bins[ray * (a.S + 1) + s], a.bins[ray * (a.S + 1) + s + 1], mc, vc);
+#endif
     } else {  // RSN_MODE_INF
       const float r2 = a.sqradius[pc];
 #pragma unroll
