@@ -624,10 +624,15 @@ __device__ __forceinline__ void store_masked_bits(const f32x16 (&acc)[NBO], floa
       const int word = m.w[nb / 2];
       const int base = (nb & 1) * 16 + 4 * q;
       float4 v;
+#ifdef RSN_DIAG_NO_EPI_VALU
+      (void)word; (void)base;
+      v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
+#else
       v.x = __uint_as_float(__float_as_uint(acc[nb][4 * q + 0]) & bit_mask(word, base + 0));
       v.y = __uint_as_float(__float_as_uint(acc[nb][4 * q + 1]) & bit_mask(word, base + 1));
       v.z = __uint_as_float(__float_as_uint(acc[nb][4 * q + 2]) & bit_mask(word, base + 2));
       v.w = __uint_as_float(__float_as_uint(acc[nb][4 * q + 3]) & bit_mask(word, base + 3));
+#endif
       xl[(nb * 4 + q) * 64] = v;
       if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
     }
@@ -646,6 +651,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
+#ifndef RSN_DIAG_NO_EPI_VALU  // (timing ablation, wrong results: the upper bound of moving this work under the next layer's MFMAs)
       if (RELU) {
         v.x = relu_f(v.x);
         v.y = relu_f(v.y);
@@ -653,6 +659,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NBO], float4* xl, 
         v.w = relu_f(v.w);
         b16 = relu_bits4(b16, v, q);
       }
+#endif
       xl[(nb * 4 + q) * 64] = v;
       if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
     }
@@ -684,6 +691,7 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, S
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v = make_float4(acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
+#ifndef RSN_DIAG_NO_EPI_VALU  // (timing ablation, wrong results: the upper bound of moving this work under the next layer's MFMAs)
       if (RELU) {
         v.x = relu_f(v.x);
         v.y = relu_f(v.y);
@@ -691,6 +699,7 @@ __device__ __forceinline__ void store_act_init(f32x16 (&acc)[NBO], float4* xl, S
         v.w = relu_f(v.w);
         b16 = relu_bits4(b16, v, q);
       }
+#endif
       xl[(nb * 4 + q) * 64] = v;
       if (sv_on(save)) sv_put<SBF>(save, nb, q, h, v);
       const float4 bv = *reinterpret_cast<const float4*>(bias + nb * 32 + 8 * q + 4 * h);
