@@ -32,7 +32,7 @@ from tools.train_parity import loss_terms, psnr, scene_rays
 
 
 def run(fixture="trainstep_trained_l8_w64", windows=6, steps=40, rays=256, eval_rays=1024, perturb=1e-6, lr_step=3000,
-        json_path="", verbose=True):
+        json_path="", verbose=True, modes=("f32",)):
     import reflect_sampling_nerf_amd as pkg
     from oracle import cpu_ref
     from reflect_sampling_nerf_amd.train_ops import exponential_decay_lr
@@ -62,14 +62,20 @@ def run(fixture="trainstep_trained_l8_w64", windows=6, steps=40, rays=256, eval_
         cfg = pkg.ReflectSamplingNeRFModelConfig(num_coarse_samples=S[0], num_importance_samples=S[1],
                                                 num_reflect_coarse_samples=S[2], num_reflect_importance_samples=S[3],
                                                 base_mlp_num_layers=layers, base_mlp_layer_width=width)
-        model = cfg.setup(scene_box=None, num_train_data=1)
-        model.field.load_state_dict(P0)
-        model.to(dev).train()
+        models = {}
+        for md in modes:  # one HIP pipeline per MMA mode (f32 exact | bf16x6 fp32-equivalent | bf16 reduced precision), same batches
+            mm = cfg.setup(scene_box=None, num_train_data=1)
+            mm.field.load_state_dict(P0)
+            mm.to(dev).train()
+            mm.field.set_mma_mode(md)
+            models[md] = mm
+        model = models[modes[0]]
         names = [n for n, _ in model.field.named_parameters()]
         Po = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
         pg = torch.Generator().manual_seed(5000 + w)
         Pp = {k: (v * (1.0 + perturb * torch.randn(v.shape, generator=pg))).clone().requires_grad_(True) for k, v in P0.items()}
-        opt_h = pkg.FusedRAdam(model.get_param_groups()["fields"], lr=1e-3, eps=1e-15)
+        opts_h = {md: pkg.FusedRAdam(mm.get_param_groups()["fields"], lr=1e-3, eps=1e-15) for md, mm in models.items()}
+        opt_h = opts_h[modes[0]]
         opt_o = torch.optim.RAdam([Po[n] for n in names], lr=1e-3, eps=1e-15)
         opt_p = torch.optim.RAdam([Pp[n] for n in names], lr=1e-3, eps=1e-15)
         erb = pkg.RayBundle(origins=eo.to(dev), directions=ed.to(dev), pixel_area=epa.to(dev), nears=near(eval_rays).to(dev),
@@ -102,6 +108,12 @@ def run(fixture="trainstep_trained_l8_w64", windows=6, steps=40, rays=256, eval_
             lg = sum(model.get_loss_dict(out, {"image": rgb.to(dev)}).values())
             lg.backward()
             opt_h.step()
+            for md in modes[1:]:
+                opts_h[md].lr = lr
+                opts_h[md].zero_grad(set_to_none=True)
+                om = models[md]._get_outputs_train(rb, jitter=jit)
+                sum(models[md].get_loss_dict(om, {"image": rgb.to(dev)}).values()).backward()
+                opts_h[md].step()
             flips += int((out["mask"].cpu() != mask_o).sum())
             rel.append((abs(float(lg) - losses[0]) / abs(losses[0]), abs(losses[1] - losses[0]) / abs(losses[0])))
         model.eval()
@@ -109,7 +121,14 @@ def run(fixture="trainstep_trained_l8_w64", windows=6, steps=40, rays=256, eval_
             og = model(erb)
         ph = (psnr(og["mid_rgb_fine"].cpu(), ergb), psnr(og["mid_reflect_fine"].cpu(), ergb))
         po, pp = oracle_psnr(Po), oracle_psnr(Pp)
-        rec = {"window": w, "psnr_hip": ph[0], "psnr_oracle": po[0], "psnr_pert": pp[0],
+        extra = {}
+        for md in modes[1:]:
+            models[md].eval()
+            with torch.no_grad():
+                ogm = models[md](erb)
+            extra["delta_%s_db" % md] = psnr(ogm["mid_rgb_fine"].cpu(), ergb) - po[0]
+            extra["delta_%s_reflect_db" % md] = psnr(ogm["mid_reflect_fine"].cpu(), ergb) - po[1]
+        rec = {**extra, "window": w, "psnr_hip": ph[0], "psnr_oracle": po[0], "psnr_pert": pp[0],
                "delta_hip_db": ph[0] - po[0], "delta_pert_db": pp[0] - po[0],
                "delta_hip_reflect_db": ph[1] - po[1], "delta_pert_reflect_db": pp[1] - po[1],
                "mask_flips_hip_vs_oracle": flips, "rel_loss_diff_first_step": rel[0], "rel_loss_diff_last_step": rel[-1],
@@ -135,6 +154,8 @@ def run(fixture="trainstep_trained_l8_w64", windows=6, steps=40, rays=256, eval_
                "psnr_of_the_trained_start_db": psnr(start["mid_rgb_fine"], ergb),
                "delta_hip_db": stats("delta_hip_db"), "delta_pert_db": stats("delta_pert_db"),
                "delta_hip_reflect_db": stats("delta_hip_reflect_db"), "delta_pert_reflect_db": stats("delta_pert_reflect_db"),
+               "hip_mode": modes[0], **{"delta_%s_db" % md: stats("delta_%s_db" % md) for md in modes[1:]},
+               **{"delta_%s_reflect_db" % md: stats("delta_%s_reflect_db" % md) for md in modes[1:]},
                "seconds": time.time() - t_start}
     summary["verdict"] = (
         "PSNR(hip) - PSNR(oracle) = %+.3f +- %.3f dB (standard error, %d windows); noise floor PSNR(oracle perturbed by "
@@ -159,9 +180,11 @@ def main():
     ap.add_argument("--eval-rays", type=int, default=1024)
     ap.add_argument("--perturb", type=float, default=1e-6)
     ap.add_argument("--json", default="")
+    ap.add_argument("--mma", default="f32", help="comma-separated MMA modes of the HIP pipelines trained in lockstep (the first one is "
+                    "`hip` in the records): f32,bf16x6,bf16")
     a = ap.parse_args()
     torch.set_num_threads(int(os.environ.get("RSN_CPU_THREADS", "16")))
-    run(a.fixture, a.windows, a.steps, a.rays, a.eval_rays, a.perturb, json_path=a.json)
+    run(a.fixture, a.windows, a.steps, a.rays, a.eval_rays, a.perturb, json_path=a.json, modes=tuple(a.mma.split(",")))
 
 
 if __name__ == "__main__":
