@@ -511,12 +511,16 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_train_kernel(const FieldJ
         float df[24];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float sx = 6.283185307179586f * mc[c];
+          // (opaque copies: hipcc otherwise forms these cosines beside the sines of the encode -- they share the argument reduction
+          // -- and carries ~100 registers of them across the whole forward through scratch: 259 -> 163 spilled registers)
+          float xm = mc[c], xv = vc[c];
+          asm volatile("" : "+v"(xm), "+v"(xv));
+          const float sx = 6.283185307179586f * xm;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const float f = fq[t];
             const float ang = sx * f;
-            const float e = expf(-0.5f * (vc[c] * (f * f)));
+            const float e = expf(-0.5f * (xv * (f * f)));
             df[c * 4 + t] = e * cos_big(ang);
             df[12 + c * 4 + t] = e * cos_big(ang + 1.5707963267948966f);
           }
