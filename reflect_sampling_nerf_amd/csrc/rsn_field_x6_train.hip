@@ -162,6 +162,9 @@ __device__ __forceinline__ void store_kstep(const RowD& d, unsigned voff, int kk
   float v[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) src(kk, i, v[2 * i], v[2 * i + 1]);
+  // (opaque here: otherwise hipcc hoists the sixteen `voff + constant` of a layer out of the layer loop -- where they can no longer
+  // become the store's immediate offset -- and carries them through scratch: 60 spill stores + 48 reloads per tile)
+  asm volatile("" : "+v"(voff));
   st16f(d, voff, kk * 128, v[0], v[1], v[2], v[3], r);
   st16f(d, voff, kk * 128 + 16, v[4], v[5], v[6], v[7], r);
 }

@@ -145,6 +145,8 @@ __device__ __forceinline__ void st16(const RowD& d, unsigned voff, unsigned soff
   // recogniser lets a VALU overwrite the data registers of a > 8-byte buffer store in the very next instruction -- LLVM's
   // createsVALUHazard: "only if not using a register in the soffset field" -- and on gfx950 that store then carries the NEW value
   // in the last quarter of every 16 lanes: found in rsn_field_x6_train.hip, round 4, where a mask temporary followed the store)
+  // (opaque: otherwise hipcc hoists `voff + constant` out of the layer loops, where it can no longer become the immediate offset)
+  asm volatile("" : "+v"(voff));
 #ifdef RSN_RT_SOFFSET_STORES  // (A/B of the round-4 form, diagnostic builds only: the offset in a scalar register)
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, v), d.r, voff, soff, RT_STORE_AUX);
 #else
