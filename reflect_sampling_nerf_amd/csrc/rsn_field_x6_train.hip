@@ -140,21 +140,7 @@ __device__ __forceinline__ void st16f(const RowD& d, unsigned voff, unsigned sof
 #endif
 #endif
 }
-template <int OFF>
-__device__ __forceinline__ u32x4t aldq(const AsyncD& d, unsigned voff) {
-#ifdef RSN_RT_NO_LOADS
-  return u32x4t{0u, 0u, 0u, 0u};
-#else
-  u32x4t v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 sc0" : "=v"(v) : "v"(voff), "s"(d.rs), "n"(OFF) : "memory");
-  return v;
-#endif
-}
 __device__ __forceinline__ void tie1(u32x2t& a) { asm volatile("" : "+v"(a)::"memory"); }
-__device__ __forceinline__ void tie8(u32x4t (&q)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(q[i])::"memory");
-}
 
 // The row piece of K-step kk (the lane's features 32 kk + 8 g .. + 7 of its point: 32 bytes at 128 kk + 32 g of the row) leaves ...
 template <class SRC, class RING>
@@ -752,13 +738,13 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
 #pragma unroll
     for (int t = 0; t < 4; ++t) fq[t] = P.freqs[4 * g + t];
     auto enc_part = [&](int l_rows) {  // (encoded-input part)^T x dy, folded into the variance gradient with the saved features
-      const AsyncD d_enc = asyncd(a.saved.enc, (long long)p0 * 512, rows, 512);
+      // ORDINARY loads (the compiler waits for them itself; twice per tile that is cheap): the destination of an inline-asm load is
+      // not safe from being spilled before its data has arrived -- seen in a forward experiment of the round, caught by the row test
+      const RowD d_enc = rowd(a.saved.enc, (long long)p0 * 512, rows, 512);
       u32x4t fr[8];
-      fr[0] = aldq<0>(d_enc, vrow * 512 + 32 * g);   fr[1] = aldq<16>(d_enc, vrow * 512 + 32 * g);
-      fr[2] = aldq<128>(d_enc, vrow * 512 + 32 * g); fr[3] = aldq<144>(d_enc, vrow * 512 + 32 * g);
-      fr[4] = aldq<256>(d_enc, vrow * 512 + 32 * g); fr[5] = aldq<272>(d_enc, vrow * 512 + 32 * g);
-      fr[6] = aldq<384>(d_enc, vrow * 512 + 32 * g); fr[7] = aldq<400>(d_enc, vrow * 512 + 32 * g);
-      r.since = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        fr[k] = __builtin_amdgcn_raw_buffer_load_b128(d_enc.r, vrow * 512 + 32 * g + (k >> 1) * 128 + (k & 1) * 16, 0, 0);
       f32x4 eacc[8];
       const SrcMasked<16> sm{G, bm};
       if (l_rows >= 0) {
@@ -767,8 +753,6 @@ __global__ __launch_bounds__(512, 2) void rsn_field_x6_bwd_kernel(const BwdJobs 
       } else {
         gemm_j<8, 8, GI_ZERO>(eacc, sm, NoNote(), r, Wf, smem, NoHook());
       }
-      wait_loads(r);
-      tie8(fr);
       float ft[24];
 #pragma unroll
       for (int u = 0; u < 24; ++u) ft[u] = __uint_as_float(fr[u >> 2][u & 3]);

@@ -169,11 +169,15 @@ __device__ __forceinline__ void st8(const RowD& d, unsigned voff, unsigned soff,
 #endif
 #endif
 }
-// Loads of what this kernel (or the forward before it) saved -- ReLU bits, encoded features -- issued a whole GEMM ahead of their
-// use as ASYNCHRONOUS inline-asm loads: hipcc knows nothing of the LDS-DMA in flight and guards a builtin load's first use with
-// vmcnt(0), which drains the ring's whole lead at every layer of a sweep.  Here the consumer waits with the ring's own
-// arithmetic: `since` counts the vector-memory operations issued behind the batch (DMA pairs, counted stores), and
-// "at most that many outstanding" = the batch has landed (vmcnt retires in order; uncounted operations only wait longer).
+// Loads of what this kernel (or the forward before it) saved -- ReLU bits, encoded features -- issued a whole GEMM ahead of their use.
+// Rounds 4a: ASYNCHRONOUS inline-asm loads with a counted wait of the ring's own arithmetic (`since`), because hipcc guards an
+// ordinary load's first use with a wait that knows nothing of the LDS-DMA in flight.  Round 4b: ORDINARY loads after all.  The
+// destination of an inline-asm load is an ordinary register to the compiler -- it may spill or copy it BEFORE the data has arrived
+// (it did, in a forward experiment: stale rows, caught by the row-level test) -- and the compiler's own wait turned out cheap: it
+// counts only the operations it knows (the hooks' buffer stores, <= 16-32 per GEMM), so `vmcnt(k)` at the first use leaves the ring's
+// DMA lead (6-10 operations) and the newest stores in flight; measured: no difference (profiles/r04_x6_ab.txt).
+// -DRSN_RT_ASM_LOADS (diagnostic builds) keeps the asm form for A/B.
+#ifdef RSN_RT_ASM_LOADS
 struct AsyncD {
   u32x4t rs;  // buffer descriptor (V#), built by hand so that it can be an inline-asm operand
 };
@@ -186,12 +190,35 @@ __device__ __forceinline__ AsyncD asyncd(const void* base, long long byte_off, i
   return d;
 }
 __device__ __forceinline__ u32x2t ald8(const AsyncD& d, unsigned voff) {
-#ifdef RSN_RT_NO_LOADS
-  return u32x2t{0xffffffffu, 0xffffffffu};
-#else
   u32x2t v;
   asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen sc0" : "=v"(v) : "v"(voff), "s"(d.rs) : "memory");
   return v;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 ald16(const AsyncD& d, unsigned voff) {
+  u32x4t v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 sc0" : "=v"(v) : "v"(voff), "s"(d.rs), "n"(OFF) : "memory");
+  return __builtin_bit_cast(bf16x8, v);
+}
+#else
+struct AsyncD {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ AsyncD asyncd(const void* base, long long byte_off, int rows, int row_bytes) {
+  AsyncD d;
+  d.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (base ? byte_off : 0), 0,
+                                          base != nullptr ? rows * row_bytes : 0, 0x00020000);
+  return d;
+}
+__device__ __forceinline__ u32x2t ald8(const AsyncD& d, unsigned voff) {
+#ifdef RSN_RT_NO_LOADS
+  return u32x2t{0xffffffffu, 0xffffffffu};
+#elif defined(RSN_RT_ASM_LOADS8)
+  u32x2t v;
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen sc0" : "=v"(v) : "v"(voff), "s"(d.r) : "memory");
+  return v;
+#else
+  return __builtin_amdgcn_raw_buffer_load_b64(d.r, voff, 0, 0);
 #endif
 }
 template <int OFF>
@@ -199,15 +226,18 @@ __device__ __forceinline__ bf16x8 ald16(const AsyncD& d, unsigned voff) {
 #ifdef RSN_RT_NO_LOADS
   return bf16x8{};
 #else
-  u32x4t v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 sc0" : "=v"(v) : "v"(voff), "s"(d.rs), "n"(OFF) : "memory");
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(d.r, voff + OFF, 0, 0));
 #endif
 }
+#endif
 // the batch issued before `r.since` was reset has landed behind this
 template <class RING>
 __device__ __forceinline__ void wait_loads(RING& r) {
+#if defined(RSN_RT_ASM_LOADS) || defined(RSN_RT_ASM_LOADS8)
   wait_vm(r.since);
+#else
+  (void)r;  // ordinary loads: the compiler waits at their first use
+#endif
 }
 __device__ __forceinline__ void tie(u32x2t& a, u32x2t& b) { asm volatile("" : "+v"(a), "+v"(b)::"memory"); }
 __device__ __forceinline__ void tie(bf16x8 (&ft)[4][2]) {
