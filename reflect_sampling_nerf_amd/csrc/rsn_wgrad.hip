@@ -26,6 +26,22 @@
 #define WG_LOAD_AUX 0
 #endif
 
+// split-bf16 stage: VALU instructions pinned in front of the first MFMA / behind every MFMA (sched_group_barrier)
+#ifndef WG_X6_HEAD
+#define WG_X6_HEAD 160
+#endif
+#ifndef WG_X6_VALU
+#define WG_X6_VALU 4
+#endif
+#ifndef WG_X6_VMEM
+#define WG_X6_VMEM 4
+#endif
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt2(float a, float b) {  // v_cvt_pk_bf16_f32: (bf16(b) << 16) | bf16(a), round to nearest even
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2w{a, b}, bf16x2w));
+}
+
 #define WG_MAX_SEG 8
 
 struct WGradArgs {
@@ -255,9 +271,70 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
   // the split-bf16 variant (BF = 3) keeps the pointer loads: with buffer loads its loop ran 5 % slower (10.8 against 10.25 ms
   // per step; its conversion VALU fills the issue slots the address arithmetic used to share)
   auto load_row_m = [&](int buf, int p, long long m0) {
+#ifdef WG_X6_PTR_LOADS
     if constexpr (BF == 3) load_row(buf, p, m0 + roff(p), true); else load_row_b(buf, p, m0);
+#else
+    load_row_b(buf, p, m0);
+#endif
+  };
+  // Two neighbouring rows / columns c0, c0 + 1 at once: their values of ONE point sit in adjacent registers (one load), so
+  // the subtractions are v_pk_add_f32 over the (c0, c0 + 1) pair while v_cvt_pk_bf16_f32 packs the point pair (2q, 2q + 1)
+  // of each: 18 VALU per 2 x 2 values.
+  auto split2 = [&](u32x4 (&o0)[3], u32x4 (&o1)[3], auto&& val) {  // val(p): the (c0, c0 + 1) values of the lane's p-th point
+    const unsigned HI = 0xffff0000u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2w xa = val(2 * q), xb = val(2 * q + 1);
+      const unsigned h0 = cvt2(xa[0], xb[0]), h1 = cvt2(xa[1], xb[1]);
+      const f32x2w ra = xa - f32x2w{__uint_as_float(h0 << 16), __uint_as_float(h1 << 16)};
+      const f32x2w rb = xb - f32x2w{__uint_as_float(h0 & HI), __uint_as_float(h1 & HI)};
+      const unsigned m0 = cvt2(ra[0], rb[0]), m1 = cvt2(ra[1], rb[1]);
+      const f32x2w sa = ra - f32x2w{__uint_as_float(m0 << 16), __uint_as_float(m1 << 16)};
+      const f32x2w sb = rb - f32x2w{__uint_as_float(m0 & HI), __uint_as_float(m1 & HI)};
+      o0[0][q] = h0; o1[0][q] = h1;
+      o0[1][q] = m0; o1[1][q] = m1;
+      o0[2][q] = cvt2(sa[0], sb[0]); o1[2][q] = cvt2(sa[1], sb[1]);
+    }
+  };
+  auto mma6 = [&](f32x16& cacc, const u32x4 (&aw)[3], const u32x4 (&bw)[3]) {  // six products, the smallest terms first
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, aw[0]), a2 = __builtin_bit_cast(bf16x8, aw[1]), a3 = __builtin_bit_cast(bf16x8, aw[2]);
+    const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[0]), b2 = __builtin_bit_cast(bf16x8, bw[1]), b3 = __builtin_bit_cast(bf16x8, bw[2]);
+    f32x16 c = cacc;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+    cacc = c;
   };
   auto mma_stage = [&](int buf) {
+#ifndef WG_X6_OLD
+    if constexpr (BF == 3) {
+      // Split-bf16: each fp32 operand value becomes three bf16 pieces (hi, mid, lo; x = hi + mid + lo to 2^-24), a PAIR of
+      // values per instruction where the hardware has one (v_cvt_pk_bf16_f32, v_pk_add_f32): 10 VALU per pair.  The 8 points
+      // of a lane x (2 rows + NKB columns) are 4 (2 + NKB) pairs per stage against 12 NKB MFMAs; a single wave per SIMD issues in
+      // order, so the splits of column block kb + 1 are written (and pinned, below) BETWEEN the 12 MFMAs of column block kb.
+      // one stage on its own (the masked tail stage of a segment): the splits of column pair j + 1 between the MFMAs of pair j
+      u32x4 av[2][3], bv[2][2][3];  // [row] / [buffer][column of the pair]: hi, mid, lo pieces as packed point pairs
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bsum[t] += fa[buf][p][t];
+      split2(av[0], av[1], [&](int p) { return f32x2w{fa[buf][p][0], fa[buf][p][1]}; });
+      split2(bv[0][0], bv[0][1], [&](int p) { return f32x2w{fb[buf][p][0], fb[buf][p][1]}; });
+#pragma unroll
+      for (int j = 0; j < NKB / 2; ++j) {
+        if (j + 1 < NKB / 2)
+          split2(bv[(j + 1) & 1][0], bv[(j + 1) & 1][1], [&](int p) { return f32x2w{fb[buf][p][2 * j + 2], fb[buf][p][2 * j + 3]}; });
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            if (t == 0 || t1_live) mma6(acc[t][2 * j + c], av[t], bv[j & 1][c]);
+      }
+    } else
+#endif
     if constexpr (BF == 3) {
       bf16x8 a1[2], a2[2], a3[2];
 #pragma unroll
@@ -363,7 +440,84 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
     }
   };
 
+#ifndef WG_X6_OLD
+  // The split-bf16 main loop, pipelined ACROSS stages: while stage s multiplies, the splits of its own later column pairs and --
+  // under its last pair -- of stage s + 1's rows and first column pair are formed, so that no split stands in front of an MFMA
+  // (a wave is alone on its SIMD: what is not slotted between MFMAs is added to them).  xa / xb01: the split rows / first column
+  // pair of the stage about to multiply.  Two fp32 stage buffers as before: stage s + 2 is loaded into stage s's buffer behind
+  // its last split.
+  u32x4 xa[BF == 3 ? 2 : 1][3], xb01[BF == 3 ? 2 : 1][3];
+  auto x6_head = [&](int buf) {
+    if constexpr (BF == 3) {
+      split2(xa[0], xa[1], [&](int p) { return f32x2w{fa[buf][p][0], fa[buf][p][1]}; });
+      split2(xb01[0], xb01[1], [&](int p) { return f32x2w{fb[buf][p][0], fb[buf][p][1]}; });
+    }
+  };
+  auto x6_stage = [&](int c, auto&& load_next2) {  // multiplies the stage in buffer c; load_next2(c) refills it
+    if constexpr (BF == 3) {
+      constexpr int NPR = NKB / 2;
+      u32x4 bq[NPR + 1][2][3], an[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bsum[t] += fa[c][p][t];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { bq[0][0][k] = xb01[0][k]; bq[0][1][k] = xb01[1][k]; }
+#ifdef WG_X6_NEAR
+      load_next2(c ^ 1);
+#endif
+#pragma unroll
+      for (int j = 0; j < NPR; ++j) {
+        if (j + 1 < NPR) {
+          split2(bq[j + 1][0], bq[j + 1][1], [&](int p) { return f32x2w{fb[c][p][2 * j + 2], fb[c][p][2 * j + 3]}; });
+        } else {
+#ifndef WG_X6_NEAR
+          load_next2(c);
+#endif
+          split2(an[0], an[1], [&](int p) { return f32x2w{fa[c ^ 1][p][0], fa[c ^ 1][p][1]}; });
+          split2(bq[NPR][0], bq[NPR][1], [&](int p) { return f32x2w{fb[c ^ 1][p][0], fb[c ^ 1][p][1]}; });
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            if (t == 0 || t1_live) mma6(acc[t][2 * j + cc], xa[t], bq[j][cc]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        xa[0][k] = an[0][k]; xa[1][k] = an[1][k];
+        xb01[0][k] = bq[NPR][0][k]; xb01[1][k] = bq[NPR][1][k];
+      }
+#ifdef WG_X6_NEAR
+      constexpr int NM = 12 * NKB, NL = 8 * (1 + (NKB >= 4 ? NKB / 4 : 1)), G0 = 0;
+#else
+      constexpr int NM = 12 * NKB, NL = 8 * (1 + (NKB >= 4 ? NKB / 4 : 1)), G0 = NM - 12 - NL > 0 ? NM - 12 - NL : 0;
+#endif
+#pragma unroll
+      for (int g = 0; g < NM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NKB == 8 ? WG_X6_VALU : WG_X6_VALU + 2, 0);  // splits
+        if (g >= G0 && g < G0 + NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one load of stage s + 2
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#endif
   auto interleave_stage = [&]() {
+#ifndef WG_X6_OLD
+    if constexpr (BF == 3) {
+      __builtin_amdgcn_sched_group_barrier(0x002, WG_X6_HEAD, 0);  // the splits of both rows and of column block 0
+#pragma unroll
+      for (int g = 0; g < 12 * NKB; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, WG_X6_VALU, 0);  // VALU of the next column block's splits / addresses
+#if WG_X6_VMEM
+        if (g % WG_X6_VMEM == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one of the next stage's loads
+#endif
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < (BF == 3 ? 96 : (BF ? 16 : WG_PAIRS * 4)); ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -407,6 +561,34 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
       }
     }
     long long j = 0;
+#if !defined(WG_X6_OLD) && !defined(WG_X6_INSTAGE)
+    if constexpr (BF == 3) {
+#ifdef WG_X6_NEAR
+      if (cnt > 0) {
+        x6_head(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll 1
+      for (; j + 1 < cnt; j += 2) {
+        x6_stage(0, [&](int c) { load_stage(c, j + 1); });
+        x6_stage(1, [&](int c) { load_stage(c, j + 2); });
+      }
+      if (j < cnt) x6_stage(0, [&](int c) { load_stage(c, j + 1); });
+#else
+      if (cnt > 0) {
+        load_stage(1, 1);
+        x6_head(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll 1
+      for (; j + 1 < cnt; j += 2) {
+        x6_stage(0, [&](int c) { load_stage(c, j + 2); });
+        x6_stage(1, [&](int c) { load_stage(c, j + 3); });
+      }
+      if (j < cnt) x6_stage(0, [&](int c) { load_stage(c, j + 2); });  // (its look-ahead works on a repeat of the last stage: unused)
+#endif
+    } else
+#endif
     if constexpr (NBUF == 4) {
 #pragma unroll 1
       for (; j + 3 < cnt; j += 4) {
