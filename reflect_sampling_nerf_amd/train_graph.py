@@ -580,6 +580,16 @@ class GetOutputsTrain(torch.autograd.Function):
         check(lib.rsn_reflect_backward(R, ptr(nm), ptr(rs["ray_index"]), ptr(rs["n_dot_d"]), ptr(cf["roughness"]),
                                        ptr(gout["d_input"]), ptr(g_pa2), ptr(g_r), ops._stream()))
         g_rough_ray += g_r
+        if getattr(model, "weight_grad_groups", 1) == 2 and not getattr(model, "_keep_train_state", False):
+            # Opt-in memory bound: the reflect branch's weight gradients are reduced NOW (six more reduction launches per step, each
+            # with its own flush) and its saved rows and sweep outputs -- a third of the step's memory -- are released before the
+            # primary levels' sweep outputs are allocated (the caching allocator hands them the same blocks; one stream: no race).
+            _weight_grads(fld, pending, acc)
+            pending = []
+            for lv in (st["lrf"], st["lrc"]):
+                lv.pop("saved", None)
+            st["inf_saved"] = None
+            del gouts, gout, jobs, go, lv
 
         # fine primary level (+ the live accumulation of the non-reflected rays' default reflect colour)
         lf = st["lf"]

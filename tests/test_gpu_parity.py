@@ -1449,6 +1449,41 @@ def test_training_step_issues_no_device_to_host_read(dev):
     assert outputs["depth_reflect_fine"].shape == (M, 1) and "depth_reflect_fine" in outputs.keys()
 
 
+@pytest.mark.parametrize("mma", ["f32", "bf16x6"])
+def test_weight_grad_groups_two_equals_one(dev, mma):
+    """Opt-in `model.weight_grad_groups = 2` (train_graph backward): the reflect branch's weight gradients are reduced right behind
+    its backward sweeps and its saved rows / sweep outputs are released before the primary levels' sweep outputs are allocated.
+    Same sample draws, same reductions in two launches per layer instead of one: gradients equal to the order of the atomics,
+    peak memory lower, still no device-to-host read in the step."""
+    from reflect_sampling_nerf_amd.parallel import train_step
+
+    R = 704
+    grads, peak = {}, {}
+    for groups in (1, 2):
+        model, rb, batch = _train_setup(dev, R, (16, 16, 16, 16), layers=8, width=256, bias_shift=1.0)
+        model.field.set_mma_mode(mma)
+        model.weight_grad_groups = groups
+        opt = pkg.FusedRAdam(model.get_param_groups()["fields"], lr=0.0, eps=1e-15)
+        torch.manual_seed(5)
+        train_step(model, rb, batch, opt, None, 100)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            torch.manual_seed(77)
+            train_step(model, rb, batch, opt, None, 110)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        peak[groups] = torch.cuda.max_memory_allocated()
+        grads[groups] = {n: p.grad.clone() for n, p in model.field.named_parameters() if p.grad is not None}
+        assert 0 < model._last_num_reflected < R
+    assert sorted(grads[1]) == sorted(grads[2])
+    for n, g0 in grads[1].items():
+        assert float((grads[2][n] - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12, n
+    assert peak[2] < 0.9 * peak[1], peak
+
+
 def test_reflect_capacity_auto_equals_full_size_buffers(dev):
     """Opt-in `model.reflect_capacity = "auto"` (train_graph.reflect_capacity): the two reflect levels -- a third of the step's
     memory -- are sized for 1.25 x the PREVIOUS step's reflected-ray count (copied to pinned memory asynchronously, looked at one
