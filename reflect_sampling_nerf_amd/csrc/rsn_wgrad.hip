@@ -1067,6 +1067,199 @@ __global__ __launch_bounds__(256) void rsn_wgrad_x6s_kernel(const WGradJobs J) {
 //   chip is power-limited: what a part costs is its energy, not its issue slots, and no placement hides it.
 #endif  // WG_X6_STAGED
 
+// ------------------------------------------------------------------------------------------------------------------------
+// rsn_wgrad_f32s_kernel (DIAGNOSTIC BUILDS ONLY, -DWG_F32_STAGED: correct, measured, not adopted): the EXACT-fp32 reduction for
+// outputs of more than 128 rows with the operand rows staged through LDS.
+// Hypothesis: the exact kernel is not power-limited (2.3 GHz), so what its per-wave loads cost (12 %: 246 us without them against
+// 281, section header) would be matrix-pipe issue time -- 24 vector-memory instructions per 64 MFMAs and wave, because every wave
+// fetches the whole X row for itself.  Here a stage (8 points: 8 KiB of
+// dY rows + 8 NKB/8 KiB of X rows) exists once per workgroup in a ring of 4 LDS slots: per stage a wave issues 3-4 global loads
+// (its quarter of the rows, three stages ahead, through a two-stage register ring), 3-4 ds_write_b128 and 12 conflict-free LDS
+// reads, and meets ONE workgroup barrier.  Same MFMA shape, fragment meaning and flush as rsn_wgrad_kernel<.,true,true,0>
+// (lane i: rows 2 i, 2 i + 1 of the wave's 64; columns 4 i .. 4 i + 3 and 128 + 4 i .. -- a free permutation, undone at the flush);
+// rows beyond a segment's end read as zeros through the descriptor's range check (row offset in the VECTOR offset).
+#ifdef WG_F32_STAGED
+template <int NKB>
+__global__ __launch_bounds__(256) void rsn_wgrad_f32s_kernel(const WGradJobs J) {
+  static_assert(NKB == 8 || NKB == 4, "column blocks: 8 (k_in <= 256) or 4 (k_in <= 128)");
+  constexpr int XROW = NKB * 128, XOFF = 8 * 1024, SLOT = XOFF + 8 * XROW, NS = 4;
+  constexpr int NDX = NKB == 8 ? 2 : 1, NLD = 2 + NDX;  // 1 KiB pieces per wave and stage
+  __shared__ __attribute__((aligned(1024))) char smem[NS * SLOT];
+  const int n_jobs = J.n_jobs;
+  const WGradArgs& a = J.j[blockIdx.x % n_jobs];  // workgroup-uniform
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int nb0 = wid * 2;
+  const long long G = gridDim.x / n_jobs, g = blockIdx.x / n_jobs;
+
+  f32x16 acc[2][NKB];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][kb][r] = 0.0f;
+  float bsum[2] = {0.0f, 0.0f};
+
+  const int n_even = a.n_out + (a.n_out & 1);
+  int c0 = nb0 * 32 + 2 * i;
+  c0 = c0 < n_even - 2 ? c0 : n_even - 2;  // clamped into the live rows: duplicates are never flushed
+  // the lane's point of pair p is 2 p + h
+  const unsigned rd_dy = (unsigned)(h * 1024 + c0 * 4);
+  const unsigned rd_x = (unsigned)(XOFF + h * XROW + 16 * i);
+
+  struct Frag {
+    f32x2w a[4];     // [pair]: rows 2 i, 2 i + 1
+    float4 b[4][NKB / 4];
+  };
+  Frag F0, F1;
+  u32x4w R[2][NLD];  // a wave's pieces of two stages on their way global memory -> LDS
+
+  long long vprefix = 0;
+  bool any = false;
+#pragma unroll 1
+  for (int s = 0; s < a.n_seg; ++s) {
+    long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
+    if (a.n_dev[s]) {  // device-side row count (no host read in the training step): uniform
+      const long long nd = (long long)(*a.n_dev[s]) * a.per_count[s];
+      n_s = nd < n_s ? (nd > 0 ? nd : 0) : n_s;
+    }
+    const long long n_st = (n_s + 7) / 8;
+    const long long first = ((g - vprefix) % G + G) % G;
+    const int cnt = (int)(first < n_st ? (n_st - first + G - 1) / G : 0);
+    vprefix += n_st;
+    if (cnt == 0) continue;  // workgroup-uniform
+    any = true;
+    const __amdgpu_buffer_rsrc_t rb_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy[s]), 0, (int)(n_s * a.ld_dy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x[s]), 0, (int)(n_s * a.ld_x * 4), 0x00020000);
+    unsigned vdy[2], vx[NDX];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) vdy[q] = (unsigned)((first * 8 + 2 * wid + q) * a.ld_dy * 4) + 16u * lane;
+#pragma unroll
+    for (int q = 0; q < NDX; ++q)
+      vx[q] = NKB == 8 ? (unsigned)((first * 8 + 2 * wid + q) * a.ld_x * 4) + 16u * lane
+                       : (unsigned)((first * 8 + 2 * wid + h) * a.ld_x * 4) + 16u * i;
+    const unsigned adv_dy = (unsigned)(G * 8 * a.ld_dy * 4), adv_x = (unsigned)(G * 8 * a.ld_x * 4);
+    auto load1 = [&](int buf, int k) {
+      if (k < 2) {
+        R[buf][k] = __builtin_amdgcn_raw_buffer_load_b128(rb_dy, vdy[k], 0, 0);
+        vdy[k] += adv_dy;
+      } else {
+        R[buf][k] = __builtin_amdgcn_raw_buffer_load_b128(rb_x, vx[k - 2], 0, 0);
+        vx[k - 2] += adv_x;
+      }
+    };
+    auto write1 = [&](int slot, int buf, int k) {
+      const unsigned d = (unsigned)slot * SLOT + 16u * lane +
+                         (k < 2 ? (unsigned)((2 * wid + k) * 1024) : XOFF + (unsigned)((2 * wid + (k - 2)) * XROW));
+      *reinterpret_cast<u32x4w*>(smem + d) = R[buf][k];
+    };
+    auto read_frag = [&](Frag& F, unsigned so) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        F.a[p] = *reinterpret_cast<const f32x2w*>(smem + so + rd_dy + p * 2048);
+#pragma unroll
+        for (int q = 0; q < NKB / 4; ++q) F.b[p][q] = *reinterpret_cast<const float4*>(smem + so + rd_x + p * 2 * XROW + q * 512);
+      }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (everyone is done reading the previous segment's slots)
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) load1(0, q);
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) load1(1, q);
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) write1(0, 0, q);
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) write1(1, 1, q);
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) load1(0, q);  // stage 2
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    read_frag(F0, 0);
+
+    // stage st: multiplies the fragments read during stage st - 1, reads stage st + 1's, writes stage st + 2's pieces (loaded during
+    // stage st - 1) to their slot and loads stage st + 3's
+    auto stage = [&](Frag& P, Frag& N, int st, int par) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage st + 1 is in LDS for everyone, stage st - 2's slot is free
+      read_frag(N, (unsigned)((st + 1) & (NS - 1)) * SLOT);
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        write1((st + 2) & (NS - 1), par, k);
+        load1(par ^ 1, k);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        bsum[0] += P.a[p][0];
+        bsum[1] += P.a[p][1];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            const float4 bv = P.b[p][kb >> 2];
+            const float b = (kb & 3) == 0 ? bv.x : (kb & 3) == 1 ? bv.y : (kb & 3) == 2 ? bv.z : bv.w;
+            acc[t][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(P.a[p][t], b, acc[t][kb], 0, 0, 0);
+          }
+      }
+      constexpr int NDS = 4 * (1 + NKB / 4);
+#pragma unroll
+      for (int m = 0; m < NDS + 2 * NLD; ++m) {  // one memory instruction behind each of the first MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (m < NDS + NLD) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int st = 0;
+#pragma unroll 1
+    for (; st + 1 < cnt; st += 2) {
+      stage(F0, F1, st, 0);
+      stage(F1, F0, st + 1, 1);
+    }
+    if (st < cnt) stage(F0, F1, st, 0);
+  }
+  if (!any) return;  // workgroup-uniform
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the ring's memory becomes the flush tiles
+#ifdef RSN_DIAG_WG_NO_FLUSH  // timing ablation (wrong results): what the atomic flush costs
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
+  float* trw = reinterpret_cast<float*>(smem) + (wid * 2 + h) * (NKB * 32);
+  int cdst[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int k = kb * 32 + i;
+    cdst[kb] = -1;
+    if (k < a.k_in) cdst[kb] = a.col_map ? a.col_map[k] : k;
+  }
+  const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc(a.dw, 0, a.n_out * a.ld_dw * 4, 0x00020000);
+  unsigned vdw[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) vdw[kb] = cdst[kb] >= 0 ? (unsigned)((8 * h * a.ld_dw + cdst[kb]) * 4) : 0x40000000u;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int slot0 = (r & 3) + 8 * (r >> 2);  // + 4 h: in vdw
+      const int n0 = nb0 * 32 + 2 * slot0 + t;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) trw[(kb < 4 ? 0 : 128) + 4 * i + (kb & 3)] = acc[t][kb][r];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const float v = trw[kb * 32 + i];
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rdw, vdw[kb] + (unsigned)(n0 * a.ld_dw * 4), 0u, 0);
+      }
+    }
+    if (a.db) {
+      const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+      const int n = nb0 * 32 + 2 * i + t;
+      if (h == 0 && n < a.n_out) atomicAdd(&a.db[n], v);
+    }
+  }
+}
+// Measured (profiles/r04_wgrad_x6.txt, section 4): 608-614 us against the register kernel's 604 us per 256 x 256 x 524,288-point
+// reduction, 359 against 343-352 us at 256 x 104: a sixth of the vector-memory instructions, the same time.  Not adopted.
+#endif  // WG_F32_STAGED
+
 static int wgrad_launch(WGradJobs& J, void* stream, int mode = 0, int operand_bf16 = 0) {
   WGradArgs& a = J.j[0];  // the jobs of a launch share shape, leading dimensions and segment lengths (checked by the caller)
   const bool xb = (operand_bf16 & 1) != 0, db = (operand_bf16 & 2) != 0;  // rows that ARE bf16 in memory
@@ -1124,6 +1317,25 @@ static int wgrad_launch(WGradJobs& J, void* stream, int mode = 0, int operand_bf
       hipLaunchKernelGGL((rsn_wgrad_x6s_kernel<4>), dim3((unsigned)grid), dim3(256), 0, st, J);
     RSN_HIP(hipGetLastError());
     return RSN_OK;
+  }
+#endif
+#ifdef WG_F32_STAGED
+  {
+    bool st32 = xv && dv && !bf16 && a.n_out > 128 && nkb >= 4 && a.ld_x % 4 == 0 && a.ld_dy % 4 == 0;
+    for (int jb = 0; jb < J.n_jobs && st32; ++jb)
+      for (int s = 0; s < a.n_seg; ++s) {
+        const long long n_s = a.seg_begin[s + 1] - a.seg_begin[s];
+        st32 = st32 && (uintptr_t)J.j[jb].x[s] % 16 == 0 && (uintptr_t)J.j[jb].dy[s] % 16 == 0 &&
+               n_s * a.ld_x * 4 < (1ll << 31) - (1ll << 27) && n_s * a.ld_dy * 4 < (1ll << 31) - (1ll << 27);
+      }
+    if (st32) {
+      if (nkb == 8)
+        hipLaunchKernelGGL((rsn_wgrad_f32s_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, J);
+      else
+        hipLaunchKernelGGL((rsn_wgrad_f32s_kernel<4>), dim3((unsigned)grid), dim3(256), 0, st, J);
+      RSN_HIP(hipGetLastError());
+      return RSN_OK;
+    }
   }
 #endif
 #define RSN_WG(NKBV)                                                                                           \
