@@ -519,6 +519,17 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
       return;
     }
 #endif
+#ifdef WG_F32_SPREAD
+    if constexpr (BF == 0 && XV && DV) {  // one load behind each of the first MFMAs (hipcc otherwise issues them in blocks of 4-8)
+#pragma unroll
+      for (int g = 0; g < WG_PAIRS * 2 * (1 + NKB / 4); ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, WG_F32_SPREAD, 0);
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < (BF == 3 ? 96 : (BF ? 16 : WG_PAIRS * 4)); ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
