@@ -19,7 +19,7 @@
     defined(RSN_DIAG_NO_SAVED_ROWS) || defined(RSN_DIAG_WG_NO_FLUSH) || defined(RSN_DIAG_X6_SAMEW) || \
     defined(RSN_RT_NO_STORES) || defined(RSN_RT_UNCOUNTED) || defined(RSN_RT_NO_LOADS) || defined(RSN_RT_NO_BITS) || \
     defined(RSN_RT_NO_SWEEP) || defined(RSN_RT_NO_PREP) || defined(RSN_RT_SOFFSET_STORES) || defined(RSN_F32_RING_TRAIN) || defined(RSN_F32_NO_WAIT) || defined(RSN_RT_NO_WAIT) || defined(RSN_RT_NO_BARRIER) || defined(RSN_DIAG_NO_EPI_VALU) || defined(RSN_RT_ASM_LOADS) || \
-    defined(WG_X6_STAGED) || defined(WG_F32_STAGED) || defined(WG_F32_SPREAD) || defined(WG_X6_OLD) || defined(WG_X6_INSTAGE) || defined(WG_X6_NEAR) || defined(WG_X6_PTR_LOADS) || defined(WGS_DMA) || \
+    defined(WG_X6_STAGED) || defined(WG_F32_STAGED) || defined(WG_F32_SPREAD) || defined(WG_X6_EXTRA) || defined(WG_X6_VALU4) || defined(WG_X6_VALU2) || defined(WG_X6_OLD) || defined(WG_X6_INSTAGE) || defined(WG_X6_NEAR) || defined(WG_X6_PTR_LOADS) || defined(WGS_DMA) || \
     defined(WGS_NO_SPLIT) || defined(WGS_NO_MFMA) || defined(WGS_NO_DMA) || defined(WGS_NO_ISSUE) || defined(WGS_NO_BARRIER) || defined(WGS_NO_WAIT) || \
     defined(RSN_F32_NO_BARRIER)
 #error "timing-diagnostic macros need -DRSN_DIAG_BUILD (tools/_variant.py): they never go into librsn_hip.so"

@@ -33,6 +33,12 @@
 #ifndef WG_X6_VALU
 #define WG_X6_VALU 4
 #endif
+#ifndef WG_X6_VALU4
+#define WG_X6_VALU4 5  // 4 column blocks (k_in <= 128): measured 253 us against 275 with 6 (256 x 104 over 524,288 points)
+#endif
+#ifndef WG_X6_VALU2
+#define WG_X6_VALU2 4
+#endif
 #ifndef WG_X6_VMEM
 #define WG_X6_VMEM 4
 #endif
@@ -497,7 +503,10 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
 #pragma unroll
       for (int g = 0; g < NM; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, NKB == 8 ? WG_X6_VALU : WG_X6_VALU + 2, 0);  // splits
+        __builtin_amdgcn_sched_group_barrier(0x002, NKB == 8 ? WG_X6_VALU : (NKB == 4 ? WG_X6_VALU4 : WG_X6_VALU2), 0);  // splits
+#ifdef WG_X6_EXTRA
+        if (NKB == 8 && g % WG_X6_EXTRA == 0) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+#endif
         if (g >= G0 && g < G0 + NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one load of stage s + 2
       }
       __builtin_amdgcn_sched_barrier(0);
