@@ -14,6 +14,18 @@ from typing import Any, Dict, Optional, Type
 import torch
 from torch import Tensor, nn
 
+try:  # pragma: no cover
+    from nerfstudio.utils.math import Gaussians  # type: ignore
+except ImportError:
+
+    @dataclass
+    class Gaussians:
+        """Stand-in for nerfstudio.utils.math.Gaussians: what a SpatialDistortion receives and returns (field.py:92-95)."""
+
+        mean: Tensor
+        cov: Tensor
+
+
 try:  # pragma: no cover - nerfstudio is not installed in the build image
     from nerfstudio.cameras.rays import RayBundle  # type: ignore
     from nerfstudio.fields.base_field import Field  # type: ignore

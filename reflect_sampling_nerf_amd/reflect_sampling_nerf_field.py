@@ -80,11 +80,12 @@ class ReflectSamplingNeRFNerfField(Field):
             raise NotImplementedError("the HIP field kernel fuses NeRFEncoding(3, 16, 0.0, max, include_input=True)")
         if self.direction_encoding.get_out_dim() != 34:
             raise NotImplementedError("the HIP field kernel fuses the 34-channel IntegratedSHEncoding")
-        if spatial_distortion is not None:
-            raise NotImplementedError("spatial_distortion is None in the reference model (model.py:103-106)")
         if head_mlp_num_layers != 1:
             raise NotImplementedError("head_mlp_num_layers != 1 is not fused (reference default: 1)")
-        self.spatial_distortion = None
+        # field.py:49,92-94: applied to the Gaussians in get_blob.  The reference model passes None (model.py:103-106); a field
+        # built with one serves the granular API (get_blob -> contract -> get_density -> heads); the fused level kernels build
+        # their Gaussians in-kernel and refuse it (_no_distortion).
+        self.spatial_distortion = spatial_distortion
         self.skip_connections = tuple(skip_connections or ())
         if len([s for s in self.skip_connections if 0 < s <= base_mlp_num_layers - 1]) > 1:
             raise NotImplementedError("at most one live skip connection is fused")
@@ -209,6 +210,7 @@ class ReflectSamplingNeRFNerfField(Field):
                           n_dev: Optional[Tensor] = None, full: bool = True) -> Dict[str, Tensor]:
         """One sampling level.  origins/directions [R,3], pixel_area [R], euclid_bins [R,S+1] ->
         per-sample sigma [R,S], color [R,S,3] and (full) pred_normals, n_dot_d, diff, tint, roughness."""
+        self._no_distortion()
         lib = _abi.load_library()
         R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
         dev = origins.device
@@ -230,6 +232,7 @@ class ReflectSamplingNeRFNerfField(Field):
                                 work: Optional[Dict] = None) -> Dict[str, Tensor]:
         """Training-mode level: same per-sample outputs as evaluate_frustums plus `raw_density`, the analytic
         `normals` (Field.get_normals, when want_normals) and `saved` = the activations the backward pass needs."""
+        self._no_distortion()
         lib = _abi.load_library()
         R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1
         N, W, L = R * S, self.width, self.mlp_base.num_layers
@@ -265,6 +268,7 @@ class ReflectSamplingNeRFNerfField(Field):
         field.py:190-201).  Both depend only on the secondary rays; as jobs of one launch get_inf_color's few tiles fill
         the level's last, partial round of tiles instead of occupying a launch of their own.
         -> (level dict as evaluate_frustums_train(want_normals=False), inf rgb [R,3], inf saved)."""
+        self._no_distortion()
         lib = _abi.load_library()
         R, S = euclid_bins.shape[0], euclid_bins.shape[1] - 1  # R here: the rays the LEVEL is sized for
         # get_inf_color runs on ALL secondary rays (`inf_directions` / sqradius may be longer than the level's inputs when the
@@ -400,7 +404,18 @@ class ReflectSamplingNeRFNerfField(Field):
         mean = torch.empty(n, 3, device=o.device)
         cov = torch.empty(n, 3, 3, device=o.device)
         check(lib.rsn_gaussians(n, ptr(o), ptr(d), ptr(pa), ptr(t0), ptr(t1), ptr(mean), ptr(cov), ops._stream()))
-        return mean.reshape(*shp, 3), cov.reshape(*shp, 3, 3)
+        mean, cov = mean.reshape(*shp, 3), cov.reshape(*shp, 3, 3)
+        if self.spatial_distortion is not None:  # field.py:93-94
+            from .nerfstudio_compat import Gaussians
+
+            g = self.spatial_distortion(Gaussians(mean=mean, cov=cov))
+            mean, cov = g.mean, g.cov
+        return mean, cov
+
+    def _no_distortion(self) -> None:
+        if self.spatial_distortion is not None:
+            raise NotImplementedError("the fused level kernels form the conical-frustum Gaussians in-kernel: a field with a "
+                                      "spatial_distortion serves the granular API only (get_blob, contract, get_density, heads)")
 
     def contract(self, mean: Tensor, cov: Tensor, mask_return: bool = False):
         """field.py:98-119: mip-NeRF-360 contraction of Gaussians (J cov J, diagonal clamped >= 0)."""

@@ -671,6 +671,38 @@ def test_get_outputs_bf16_ring_kernel_all_modes(dev):
 
 
 # ---------------------------------------------------------------------------------------------- granular Field API
+def test_field_spatial_distortion_in_the_granular_api(dev):
+    """field.py:49,92-94: a Field built with a `spatial_distortion` applies it to the Gaussians in get_blob (here: the reference's own
+    contraction wrapped as a distortion, so the result is checkable against the golden-pinned `contract`); the fused level kernels,
+    which form their Gaussians in-kernel, refuse such a field instead of ignoring the knob."""
+    from types import SimpleNamespace
+
+    plain, _, _ = make_field(8, 128, dev, seed=21)
+    seen = {}
+
+    class Contract360:
+        def __call__(self, g):
+            seen["type"] = type(g).__name__
+            m, c = plain.contract(g.mean, g.cov)
+            return type(g)(mean=m, cov=c)
+
+    torch.manual_seed(21)
+    fld = pkg.ReflectSamplingNeRFNerfField(base_mlp_num_layers=8, base_mlp_layer_width=128, spatial_distortion=Contract360()).to(dev)
+    R, S = 5, 6
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=5)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    _, eb = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S, None)
+    t0, t1 = eb[:, :-1], eb[:, 1:]
+    fr = SimpleNamespace(origins=o[:, None, :].to(dev), directions=d[:, None, :].to(dev), starts=t0[..., None].to(dev),
+                         ends=t1[..., None].to(dev), pixel_area=pa[:, None, :].to(dev))
+    mean, cov = fld.get_blob(SimpleNamespace(frustums=fr))
+    assert seen["type"] == "Gaussians"
+    mean_ref, cov_ref = cpu_ref.contract(*cpu_ref.gaussian_blob(o, d, pa, t0, t1))
+    assert max_abs(mean.cpu(), mean_ref) <= 2e-6 and max_abs(cov.cpu(), cov_ref) <= 2e-6
+    with pytest.raises(NotImplementedError, match="granular API"):
+        fld.evaluate_frustums(o.to(dev), d.to(dev), pa.reshape(-1).to(dev), eb.to(dev))
+
+
 def test_granular_field_api(dev):
     """The Field methods the reference Model calls one by one: get_blob, contract, get_density,
     get_pred_normals, get_diff, get_tint, get_roughness, get_mid, get_low, get_reflection -- against the oracle, and
