@@ -184,6 +184,32 @@ def test_diagnostic_macros_cannot_enter_the_product_library(tmp_path):
     bad = subprocess.run(base + ["-DRSN_R16_NO_MFMA"], capture_output=True, text=True)
     assert bad.returncode != 0 and "RSN_DIAG_BUILD" in bad.stderr
     assert subprocess.run(base + ["-DRSN_R16_NO_MFMA", "-DRSN_DIAG_BUILD"], capture_output=True).returncode == 0
+    # the LDS-staged weight-gradient probe kernels (csrc/rsn_wgrad_staged_probe.h) are diagnostic builds only as well
+    for macro in ("-DWG_X6_STAGED", "-DWG_F32_STAGED"):
+        bad = subprocess.run(base + [macro], capture_output=True, text=True)
+        assert bad.returncode != 0 and "RSN_DIAG_BUILD" in bad.stderr, macro
+    blob = open(os.path.join(REPO, "reflect_sampling_nerf_amd", "librsn_hip.so"), "rb").read()
+    assert b"rsn_wgrad_x6s_kernel" not in blob and b"rsn_wgrad_f32s_kernel" not in blob
+
+
+def test_field_constructor_knobs():
+    """reference field.py:38-47: `spatial_distortion` is accepted and kept (applied in get_blob: GPU test); the knobs the fused
+    kernels do not cover are refused loudly instead of being ignored."""
+    import pytest
+
+    from reflect_sampling_nerf_amd.nerfstudio_compat import Gaussians
+
+    fn = lambda g: g  # noqa: E731
+    fld = pkg.ReflectSamplingNeRFNerfField(base_mlp_num_layers=4, base_mlp_layer_width=64, spatial_distortion=fn)
+    assert fld.spatial_distortion is fn
+    with pytest.raises(NotImplementedError, match="granular API"):
+        fld._no_distortion()
+    g = Gaussians(mean=torch.zeros(2, 3), cov=torch.zeros(2, 3, 3))
+    assert g.mean.shape == (2, 3) and g.cov.shape == (2, 3, 3)
+    with pytest.raises(NotImplementedError):
+        pkg.ReflectSamplingNeRFNerfField(head_mlp_num_layers=2)
+    with pytest.raises(NotImplementedError):
+        pkg.ReflectSamplingNeRFNerfField(skip_connections=(2, 4))
 
 
 def test_product_library_reads_no_environment_switches():
