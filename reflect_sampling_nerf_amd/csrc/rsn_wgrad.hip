@@ -275,8 +275,9 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
       for (int kb = 0; kb < NKB; ++kb) fb[buf][p][kb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[kb], sx, WG_LOAD_AUX));
     }
   };
-  // the split-bf16 variant (BF = 3) keeps the pointer loads: with buffer loads its loop ran 5 % slower (10.8 against 10.25 ms
-  // per step; its conversion VALU fills the issue slots the address arithmetic used to share)
+  // every variant loads through the buffer form.  (Round 3 kept pointer loads for the split-bf16 variant -- 5 % faster then, when its
+  // splits stood in blocks in front of the MFMAs; with the splits pinned between the MFMAs the 30 address registers are worth more.
+  // -DWG_X6_PTR_LOADS keeps the old form for A/B in diagnostic builds.)
   auto load_row_m = [&](int buf, int p, long long m0) {
 #ifdef WG_X6_PTR_LOADS
     if constexpr (BF == 3) load_row(buf, p, m0 + roff(p), true); else load_row_b(buf, p, m0);
@@ -318,11 +319,10 @@ __global__ __launch_bounds__(256) void rsn_wgrad_kernel(const WGradJobs J) {
   auto mma_stage = [&](int buf) {
 #ifndef WG_X6_OLD
     if constexpr (BF == 3) {
-      // Split-bf16: each fp32 operand value becomes three bf16 pieces (hi, mid, lo; x = hi + mid + lo to 2^-24), a PAIR of
-      // values per instruction where the hardware has one (v_cvt_pk_bf16_f32, v_pk_add_f32): 10 VALU per pair.  The 8 points
-      // of a lane x (2 rows + NKB columns) are 4 (2 + NKB) pairs per stage against 12 NKB MFMAs; a single wave per SIMD issues in
-      // order, so the splits of column block kb + 1 are written (and pinned, below) BETWEEN the 12 MFMAs of column block kb.
-      // one stage on its own (the masked tail stage of a segment): the splits of column pair j + 1 between the MFMAs of pair j
+      // Split-bf16, one stage on its own (the masked tail stage of a segment; the main loop is x6_stage below): each fp32 operand
+      // value becomes three bf16 pieces (hi, mid, lo; x = hi + mid + lo to 2^-24).  The 8 points of a lane x (2 rows + NKB columns)
+      // are 2 + NKB split2 calls per stage against 12 NKB MFMAs; a wave that is alone on its SIMD issues in order, so the splits of
+      // column pair j + 1 are written (and pinned, interleave_stage) BETWEEN the MFMAs of pair j.
       u32x4 av[2][3], bv[2][2][3];  // [row] / [buffer][column of the pair]: hi, mid, lo pieces as packed point pairs
 #pragma unroll
       for (int t = 0; t < 2; ++t)
