@@ -21,6 +21,9 @@ Pinned part: tests/test_oracle_golden.py checks this file against golden vectors
 running the *reference's own modules* (imported from /root/reference on top of the import
 shim in oracle/ns_shim/) -- see oracle/make_golden.py.  That pins rows F1-F13 exactly and
 N1-N12 up to the shim's (independent, class-shaped) restatement of nerfstudio.
+tests/test_oracle_first_principles.py checks the nerfstudio-side pieces (N3, N5, N7-N10, F2) against formulations
+that share no code with this file (Monte-Carlo moments, the front-to-back recurrence, empirical sampling
+distributions, autograd Jacobians): evidence, not a pin -- the label above stands.
 
 Everything is functional: explicit tensors in, tensors out, no nerfstudio types.  Parameters
 are a dict keyed by the reference Field's state_dict names ("mlp_base.layers.0.weight", ...).
