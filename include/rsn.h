@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSN_ABI_VERSION 15
+#define RSN_ABI_VERSION 16
 #define RSN_MAX_TRUNK_LAYERS 16
 #define RSN_NUM_FREQS 16   /* NeRFEncoding(num_frequencies=16), reflect_sampling_nerf_model.py:98-100 */
 #define RSN_ENC_DIM 99     /* 3*16*2 + 3 */
@@ -301,6 +301,16 @@ int rsn_field_forward_inf(const rsn_field_desc* desc, const float* packed, int32
 int rsn_field_forward_gaussians(const rsn_field_desc* desc, const float* packed, int32_t n_points,
                                 const float* means, const float* cov_diag, const float* view_dirs,
                                 const rsn_field_outputs* out, float* embedding, void* stream);
+
+/* rsn_field_forward_gaussians_train (ABI 16): the same evaluation in TRAINING mode -- reference field.py:122-137 with
+ * requires_density_grad=True followed by get_normals() (field.py:146-147): the saved activations of the points
+ * (rsn_field_saved, slab layout: rsn_train_saved_layout) and, in saved->normals [N,3], the analytic normals
+ * -normalize(d raw_density / d mean) of the (contracted) means handed in.  Exact-fp32 fields (mma_mode RSN_MMA_F32) only:
+ * the reduced / split precision training kernels take conical frustums, not Gaussians (RSN_ERR_UNSUPPORTED otherwise). */
+int rsn_field_forward_gaussians_train(const rsn_field_desc* desc, const float* packed, int32_t n_points,
+                                      const float* means, const float* cov_diag, const float* view_dirs,
+                                      const rsn_field_outputs* out, float* embedding, const rsn_field_saved* saved,
+                                      void* stream);
 
 /* rsn_field_forward_embedding: the head getters of the granular Field API on a caller-supplied embedding [N,W]
  * (post-ReLU trunk output, as returned by get_density): get_pred_normals, get_diff, get_tint, get_roughness

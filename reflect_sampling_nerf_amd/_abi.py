@@ -9,7 +9,7 @@ import os
 
 from ._build import LIB_PATH
 
-RSN_ABI_VERSION = 15
+RSN_ABI_VERSION = 16
 RSN_ABI_DIAG_FLAG = 0x10000  # rsn_abi_version() of a -DRSN_DIAG_BUILD library (csrc/rsn_common.h)
 RSN_MAX_TRUNK_LAYERS = 16
 RSN_NUM_FREQS = 16
@@ -178,6 +178,8 @@ _SIGNATURES = {
     "rsn_reflection": (C.c_int, [C.c_int64, _fp, _fp, _fp, _fp, C.c_void_p]),
     "rsn_field_forward_gaussians": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp,
                                               C.POINTER(FieldOutputs), _fp, C.c_void_p]),
+    "rsn_field_forward_gaussians_train": (C.c_int, [C.POINTER(FieldDesc), _fp, C.c_int32, _fp, _fp, _fp,
+                                                    C.POINTER(FieldOutputs), _fp, C.POINTER(FieldSaved), C.c_void_p]),
     "rsn_composite": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CompositeIO),
                                 C.c_void_p]),
     "rsn_reflect_workspace_bytes": (C.c_size_t, [C.c_int32]),

@@ -148,6 +148,28 @@ extern "C" int rsn_field_forward_train_jobs(const rsn_field_desc* desc, const fl
   return launch_field_jobs(desc, js, n_jobs, stream);
 }
 
+extern "C" int rsn_field_forward_gaussians_train(const rsn_field_desc* desc, const float* packed, int32_t n_points,
+                                                 const float* means, const float* cov_diag, const float* view_dirs,
+                                                 const rsn_field_outputs* out, float* embedding,
+                                                 const rsn_field_saved* saved, void* stream) {
+  RSN_REQUIRE(desc && out && saved, RSN_ERR_INVALID_ARGUMENT, "desc/out/saved is NULL");
+  RSN_REQUIRE(n_points >= 0, RSN_ERR_INVALID_ARGUMENT, "n_points=%d", n_points);
+  RSN_REQUIRE(n_points == 0 || means, RSN_ERR_INVALID_ARGUMENT, "means is NULL");
+  RSN_REQUIRE(desc->mma_mode == RSN_MMA_F32, RSN_ERR_UNSUPPORTED,
+              "training-mode evaluation of explicit Gaussians runs on the exact-fp32 kernels only (mma_mode %d)", desc->mma_mode);
+  RSN_REQUIRE(saved->act && saved->enc && saved->bott && saved->sh && saved->hid && saved->heads && saved->relu_bits,
+              RSN_ERR_INVALID_ARGUMENT, "training needs every saved-activation buffer (normals may be NULL)");
+  FieldArgs a = {};
+  a.packed = packed;
+  a.mode = RSN_MODE_GAUSS;
+  a.n_rays = n_points; a.n_dev = nullptr; a.S = 1;
+  a.means = means; a.cov_diag = cov_diag; a.view_dirs = view_dirs;
+  a.out = *out;
+  a.embedding = embedding;
+  a.saved = *saved;
+  return launch_field(desc, a, stream);
+}
+
 extern "C" int rsn_field_forward_frustum(const rsn_field_desc* desc, const float* packed, int32_t n_rays,
                                          const int32_t* n_dev, int32_t n_samples, const float* origins,
                                          const float* directions, const float* pixel_area, const float* euclid_bins,

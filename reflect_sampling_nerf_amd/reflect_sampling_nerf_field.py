@@ -357,8 +357,9 @@ class ReflectSamplingNeRFNerfField(Field):
         return out
 
     def evaluate_gaussians(self, means: Tensor, cov_diag: Optional[Tensor], view_dirs: Optional[Tensor],
-                           want_embedding: bool = False) -> Dict[str, Tensor]:
-        """Granular evaluation on explicit (already contracted) Gaussians: means [N,3], cov_diag [N,3]."""
+                           want_embedding: bool = False, want_normals: bool = False) -> Dict[str, Tensor]:
+        """Granular evaluation on explicit (already contracted) Gaussians: means [N,3], cov_diag [N,3].  want_normals: the
+        training kernel (rsn_field_forward_gaussians_train) with its analytic-normal sweep; level["normals"] [N,3]."""
         lib = _abi.load_library()
         N, dev = means.shape[0], means.device
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
@@ -367,24 +368,43 @@ class ReflectSamplingNeRFNerfField(Field):
         emb = f(N, self.width) if want_embedding else None
         fo = ops.field_outputs_struct(level)
         desc = self.field_desc()
-        check(lib.rsn_field_forward_gaussians(C.byref(desc), ptr(self.packed_weights()), N, ptr(means), ptr(cov_diag),
-                                              ptr(view_dirs), C.byref(fo), ptr(emb), ops._stream()))
+        if want_normals:
+            saved = self.alloc_saved(N, dev)
+            saved["normals"] = f(N, 3)
+            fs = _abi.FieldSaved()
+            for k in ("enc", "act", "bott", "sh", "hid", "heads", "normals", "relu_bits"):
+                setattr(fs, k, ptr(saved[k]))
+            check(lib.rsn_field_forward_gaussians_train(C.byref(desc), ptr(self.packed_weights()), N, ptr(means), ptr(cov_diag),
+                                                        ptr(view_dirs), C.byref(fo), ptr(emb), C.byref(fs), ops._stream()))
+            level["normals"] = saved["normals"]
+        else:
+            check(lib.rsn_field_forward_gaussians(C.byref(desc), ptr(self.packed_weights()), N, ptr(means), ptr(cov_diag),
+                                                  ptr(view_dirs), C.byref(fo), ptr(emb), ops._stream()))
         if emb is not None:
             level["embedding"] = emb
         return level
 
     # ------------------------------------------------------------------ reference method names (granular API)
     def get_density(self, mean: Tensor, cov: Optional[Tensor] = None, requires_density_grad: bool = False):
-        """field.py:122-137: (density [...,1], embedding [...,W]).  Eval-mode forward only; the analytic-normal
-        path (requires_density_grad in training) is served by the fused level kernels, not here."""
-        if requires_density_grad and self.training:
-            raise NotImplementedError("training-mode density gradients are only available through the fused path")
+        """field.py:122-137: (density [...,1], embedding [...,W]).  With `requires_density_grad` in training mode
+        (field.py:125-127,133-134) the analytic normals -normalize(d raw_density / d mean) of the means handed in are
+        computed by the same launch (the training kernel's in-kernel sweep) and handed out by get_normals(), as the
+        reference's autograd does it -- forward VALUES: the granular calls carry no autograd graph (training runs through
+        the model's fused graph, train_graph.py); exact-fp32 fields only."""
         shp = mean.shape[:-1]
         m = ops._f32c(mean.reshape(-1, 3))
         cd = None
         if cov is not None:
             cd = ops._f32c(torch.diagonal(cov, dim1=-2, dim2=-1).reshape(-1, 3))
-        lv = self.evaluate_gaussians(m, cd, None, want_embedding=True)
+        self._normals = None
+        if requires_density_grad and self.training:
+            if int(self.mma_mode) != _abi.RSN_MMA_F32:
+                raise NotImplementedError("get_density(requires_density_grad=True) on explicit Gaussians runs on the exact-fp32 "
+                                          "kernels only (set_mma_mode('f32')); the other modes train through the fused path")
+            lv = self.evaluate_gaussians(m, cd, None, want_embedding=True, want_normals=True)
+            self._normals = lv.pop("normals").reshape(*shp, 3)
+        else:
+            lv = self.evaluate_gaussians(m, cd, None, want_embedding=True)
         lv["embedding"] = lv["embedding"][:, : self.param_width]  # the kernels' padded units (exact zeros) are not part of the API
         self._last_level = {k: v.reshape(*shp, -1) for k, v in lv.items()}
         return self._last_level["sigma"], self._last_level["embedding"]
@@ -468,9 +488,14 @@ class ReflectSamplingNeRFNerfField(Field):
         return self._heads(embedding)["pred_normals"]
 
     def get_normals(self) -> Tensor:
-        """field.py:146-147: analytic normals need the training graph; the fused training forward returns them as
-        outputs["normals_*"] (rsn_field_forward_frustum_train)."""
-        raise NotImplementedError("analytic normals are produced by the fused training forward (outputs['normals_*'])")
+        """field.py:146-147 -> nerfstudio Field.get_normals: -normalize(d density-before-activation / d sample locations) of
+        the last get_density(mean, cov, requires_density_grad=True) call in training mode (the model's fused training
+        forward returns its own as outputs["normals_*"])."""
+        n = getattr(self, "_normals", None)
+        if n is None:
+            raise RuntimeError("get_normals(): call get_density(mean, cov, requires_density_grad=True) in training mode first "
+                               "(reference field.py:125-127)")
+        return n
 
     def get_roughness(self, embedding: Tensor, activation: Optional[nn.Module] = None) -> Tensor:
         """field.py:150-155: activation(roughness head); default Sigmoid."""

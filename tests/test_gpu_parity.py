@@ -400,6 +400,40 @@ def test_train_level_normals_and_saved_activations(dev, layers, width):
     assert float((n_gpu.norm(dim=-1) - 1).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("layers,width", [(8, 128), (8, 256)])
+def test_granular_get_density_with_density_grad_and_get_normals(dev, layers, width):
+    """The reference model's own call sequence in training mode (model.py:153,160): get_density(mean, cov, True) followed by
+    get_normals() -- density, embedding and -normalize(d raw_density / d mean) of the CONTRACTED means handed in (field.py:125-127,
+    146-147), against autograd through the oracle on the same Gaussians; the other MMA modes say so instead of guessing."""
+    fld, P, fs = make_field(layers, width, dev, seed=5 * layers + width, bias_shift=1.0)
+    fld.train()
+    R, S = 9, 14
+    o, d, pa = cpu_ref.synthetic_rays(R, seed=11)
+    nears, fars = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    _, eb = cpu_ref.spaced_bins("uniform", 1.0, nears, fars, S, torch.rand(R, S + 1, generator=torch.Generator().manual_seed(4)))
+    mean, cov = cpu_ref.contract(*cpu_ref.gaussian_blob(o, d, pa, eb[:, :-1], eb[:, 1:]))
+    mean_r = mean.clone().requires_grad_(True)
+    enc = cpu_ref.ipe(fs, mean_r, torch.diagonal(cov, dim1=-2, dim2=-1))
+    sig_ref, emb_ref, raw = cpu_ref.density_from_encoding(P, fs, enc)
+    (g,) = torch.autograd.grad(raw.sum(), mean_r)
+    n_ref = -g / g.norm(dim=-1, keepdim=True)
+    with pytest.raises(RuntimeError, match="requires_density_grad"):
+        fld.get_normals()
+    sig, emb = fld.get_density(mean.to(dev), cov.to(dev), requires_density_grad=True)
+    n = fld.get_normals()
+    assert sig.shape == (R, S, 1) and emb.shape == (R, S, width) and n.shape == (R, S, 3)
+    assert max_abs(sig.cpu(), sig_ref.detach()) <= TOL and max_abs(emb.cpu(), emb_ref.detach()) <= TOL
+    assert max_abs(n.cpu(), n_ref) <= TOL_GRAD_NORMAL and float((n.cpu() - n_ref).abs().mean()) <= 5e-5
+    assert float((n.norm(dim=-1) - 1).abs().max()) <= 1e-5
+    sig_e, _ = fld.get_density(mean.to(dev), cov.to(dev))  # without the flag: the plain forward, and no stale normals
+    assert torch.equal(sig_e, sig)
+    with pytest.raises(RuntimeError):
+        fld.get_normals()
+    fld.set_mma_mode("bf16x6")
+    with pytest.raises(NotImplementedError, match="exact-fp32"):
+        fld.get_density(mean.to(dev), cov.to(dev), requires_density_grad=True)
+
+
 # ---------------------------------------------------------------------------------------------- training: forward + backward
 def _loss_from_outputs(out, tgt):
     """A loss touching every gradient-carrying output, shaped like get_loss_dict (model.py:395-407)."""
