@@ -55,6 +55,12 @@ class IntegratedSHEncoding(nn.Module):
     def get_out_dim(self) -> int:
         return 34
 
+    @torch.no_grad()
+    def pytorch_fwd(self, directions: Tensor) -> Tensor:
+        """components.py:52-129: the 34 unattenuated real-SH components of `directions` [..., 3] (same kernel, no roughness)."""
+        assert directions.shape[-1] == 3, f"Direction input should have three dimensions. Got {directions.shape[-1]}"
+        return ops.sh34_encode(directions, None)
+
     def forward(self, directions: Tensor, roughness: Optional[Tensor] = None) -> Tensor:
         """directions [..., 3], roughness [..., 1] (or None) -> [..., 34] via rsn_sh34_encode (components.py:52-140;
         no gradient flows through the encoding in the reference either: computed under no_grad)."""

@@ -1239,6 +1239,8 @@ def test_standalone_sh34_encoding_matches_reference_golden(dev):
     o2 = enc(d2.to(dev)).cpu()
     assert o2.shape == (3, 5, 34)
     assert max_abs(o2, cpu_ref.integrated_sh(d2, torch.zeros(3, 5, 1))) <= 1e-5
+    # the unattenuated basis under the reference's method name (components.py:52-129)
+    assert torch.equal(enc.pytorch_fwd(d2.to(dev)).cpu(), o2) and max_abs(o2, cpu_ref.sh34_basis(d2)) <= 1e-5
 
 
 def test_standalone_ipe_encoding_matches_oracle(dev):
