@@ -61,10 +61,10 @@ class IntegratedSHEncoding(nn.Module):
         assert directions.shape[-1] == 3, f"Direction input should have three dimensions. Got {directions.shape[-1]}"
         return ops.sh34_encode(directions, None)
 
-    def forward(self, directions: Tensor, roughness: Optional[Tensor] = None) -> Tensor:
-        """directions [..., 3], roughness [..., 1] (or None) -> [..., 34] via rsn_sh34_encode (components.py:52-140;
+    def forward(self, in_tensor: Tensor, roughness: Optional[Tensor] = None) -> Tensor:
+        """in_tensor = directions [..., 3], roughness [..., 1] (or None) -> [..., 34] via rsn_sh34_encode (components.py:52-140;
         no gradient flows through the encoding in the reference either: computed under no_grad)."""
-        return ops.sh34_encode(directions, roughness)
+        return ops.sh34_encode(in_tensor, roughness)
 
 
 @dataclass
