@@ -171,6 +171,44 @@ class FusedRAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
+    # -- checkpoint / resume in torch.optim.RAdam's own format: a run of the reference (nerfstudio's RAdamOptimizerConfig builds
+    #    torch.optim.RAdam; its trainer saves optimizer.state_dict()) resumes here and the other way round.
+    def state_dict(self) -> dict:
+        state = {}
+        for i, (m, v) in enumerate(zip(self.exp_avg, self.exp_avg_sq)):
+            if self.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "decoupled_weight_decay": False,
+                 "foreach": None, "maximize": False, "capturable": False, "differentiable": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(self.params):
+            raise ValueError(f"optimizer state for {len(ids)} parameters, this optimizer has {len(self.params)}")
+        g0 = groups[0]
+        if any(g.get("weight_decay", 0) != 0 for g in groups):
+            raise ValueError("FusedRAdam has no weight decay (the reference trains without: config.py:50-53)")
+        self.lr, self.betas, self.eps = float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"])
+        steps = set()
+        for k, pid in enumerate(ids):  # k-th parameter of this optimizer <- state entry `pid` (torch numbers them in group order)
+            st = sd["state"].get(pid)
+            p = self.params[k]
+            if st is None:  # torch creates a parameter's state at its first gradient: none yet = zeros
+                self.exp_avg[k].zero_()
+                self.exp_avg_sq[k].zero_()
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"parameter {k}: state of shape {tuple(st['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+            self.exp_avg[k] = st["exp_avg"].detach().to(device=p.device, dtype=p.dtype).clone()
+            self.exp_avg_sq[k] = st["exp_avg_sq"].detach().to(device=p.device, dtype=p.dtype).clone()
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused kernel keeps one step count")
+        self.step_count = steps.pop() if steps else 0
+
     def current_lr(self) -> float:
         if self.lr_final is None:
             return self.lr

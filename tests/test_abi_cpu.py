@@ -225,3 +225,26 @@ def test_product_library_reads_no_environment_switches():
     nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True)
     assert nm.returncode == 0 and "getenv" not in nm.stdout
     assert b"rsn_field_bf16_ring_kernel" not in blob and b"rsn_field_bf16_ring16_kernel" in blob
+
+
+def test_fused_radam_state_dict_is_torch_radams():
+    """FusedRAdam.state_dict / load_state_dict speak torch.optim.RAdam's format (the reference's optimiser: config.py:50-53 through
+    nerfstudio's RAdamOptimizerConfig), so that checkpoints cross over; the state transfer itself needs no GPU."""
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(4, 3, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g)),
+          torch.nn.Parameter(torch.ones(2))]
+    ref = torch.optim.RAdam(ps, lr=1e-3, eps=1e-15)
+    for _ in range(3):
+        ps[0].grad, ps[1].grad = torch.randn(4, 3, generator=g), torch.randn(5, generator=g)  # ps[2]: never a gradient
+        ref.step()
+    mine = pkg.FusedRAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1.0, eps=1.0)
+    mine.load_state_dict(ref.state_dict())
+    assert mine.step_count == 3 and mine.lr == 1e-3 and mine.eps == 1e-15 and tuple(mine.betas) == (0.9, 0.999)
+    sd = ref.state_dict()["state"]
+    assert torch.equal(mine.exp_avg[0], sd[0]["exp_avg"]) and torch.equal(mine.exp_avg_sq[1], sd[1]["exp_avg_sq"])
+    assert float(mine.exp_avg[2].abs().max()) == 0.0
+    back = torch.optim.RAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1.0)
+    back.load_state_dict(mine.state_dict())
+    assert back.param_groups[0]["lr"] == 1e-3 and float(back.state_dict()["state"][0]["step"]) == 3.0
+    with pytest.raises(ValueError):
+        pkg.FusedRAdam(ps[:2]).load_state_dict(ref.state_dict())

@@ -1036,6 +1036,27 @@ def test_fused_radam_matches_torch_optim(dev):
         assert max_abs(pg.detach().cpu(), pr.detach()) <= 2e-6
     assert pkg.exponential_decay_lr(0) == 1e-3 and abs(pkg.exponential_decay_lr(50000) - 1e-4) < 1e-12
     assert abs(pkg.exponential_decay_lr(25000) - (1e-3 * 1e-4) ** 0.5) < 1e-12
+    # checkpoint / resume in torch.optim.RAdam's own state_dict format, both ways: a fresh FusedRAdam takes torch's state, a fresh
+    # torch.optim.RAdam takes FusedRAdam's, and three more steps on the same gradients keep all four trajectories together
+    ref2 = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    gpu2 = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    opt_ref2 = torch.optim.RAdam(ref2, lr=1e-3, eps=1e-15)
+    opt_ref2.load_state_dict(opt_gpu.state_dict())
+    opt_gpu2 = pkg.FusedRAdam(gpu2, lr=5e-2, eps=1e-3)  # hyper-parameters come from the checkpoint
+    opt_gpu2.load_state_dict(opt_ref.state_dict())
+    assert opt_gpu2.step_count == 12 and opt_gpu2.lr == 1e-3 and opt_gpu2.eps == 1e-15
+    for step in range(12, 15):
+        for k in range(len(shapes)):
+            gr = torch.randn(*shapes[k], generator=g) * (0.1 + step)
+            for plist in (ref_p, ref2):
+                plist[k].grad = gr.clone()
+            for plist in (gpu_p, gpu2):
+                plist[k].grad = gr.clone().to(dev)
+        for o_ in (opt_ref, opt_ref2, opt_gpu, opt_gpu2):
+            o_.step()
+    for k in range(len(ref_p)):
+        for other in (ref2[k].detach(), gpu_p[k].detach().cpu(), gpu2[k].detach().cpu()):
+            assert max_abs(other, ref_p[k].detach()) <= 3e-6, k
 
 
 @pytest.mark.parametrize("n_out,k_in,ld_dy,ld_x", [
