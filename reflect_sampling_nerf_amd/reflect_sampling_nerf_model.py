@@ -92,6 +92,19 @@ class ReflectSamplingNeRFModel(Model):
         self.near = 1.0 / 16
         self.background_color = torch.tensor([1.0, 1.0, 1.0])  # colors.WHITE
         self.rgb_loss = nn.MSELoss()
+        # Checkpoints of the reference: its Model also owns torchmetrics modules (model.py:131-133: psnr, ssim,
+        # lpips -- the LPIPS network's weights sit in every pipeline checkpoint as `_model.lpips.net.*`).  This Model has no such
+        # modules (SSIM / LPIPS are out of scope), so their entries are dropped from an incoming state dict before nn.Module's strict
+        # key check sees them -- also when the checkpoint is loaded through a parent (nerfstudio's pipeline: prefix `_model.`).
+        self._register_load_state_dict_pre_hook(self._drop_reference_metric_state)
+
+    _REFERENCE_METRIC_MODULES = ("lpips", "psnr", "ssim")
+
+    @staticmethod
+    def _drop_reference_metric_state(state_dict, prefix, *_unused) -> None:
+        drop = tuple(prefix + m + "." for m in ReflectSamplingNeRFModel._REFERENCE_METRIC_MODULES)
+        for k in [k for k in state_dict if k.startswith(drop)]:
+            del state_dict[k]
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         if self.field is None:

@@ -248,3 +248,35 @@ def test_fused_radam_state_dict_is_torch_radams():
     assert back.param_groups[0]["lr"] == 1e-3 and float(back.state_dict()["state"][0]["step"]) == 3.0
     with pytest.raises(ValueError):
         pkg.FusedRAdam(ps[:2]).load_state_dict(ref.state_dict())
+
+
+def test_reference_pipeline_checkpoint_keys_load_strictly():
+    """a pipeline checkpoint of the reference carries `_model.field.*` (names / shapes: test_state_dict_names_match_reference),
+    `_model.device_indicator_param` and the weights of the torchmetrics modules its Model owns (`_model.lpips.net.*`, model.py:131-133).
+    Loaded through a parent module with strict key checking -- as nerfstudio's pipeline does -- the metric entries are dropped, everything
+    else must match."""
+    cfg = pkg.ReflectSamplingNeRFModelConfig(base_mlp_num_layers=4, base_mlp_layer_width=64)
+
+    class Pipe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(1)
+            self._model = cfg.setup(scene_box=None, num_train_data=1)
+
+    src, dst = Pipe(), Pipe()
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(1.0)
+    ckpt = dict(src.state_dict())
+    ckpt["_model.lpips.net.net.slice1.0.weight"] = torch.zeros(64, 3, 11, 11)  # what the reference's checkpoint adds
+    ckpt["_model.lpips.net.lin0.model.1.weight"] = torch.zeros(1, 64, 1, 1)
+    res = dst.load_state_dict(ckpt, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (n, a), (_, b) in zip(src.named_parameters(), dst.named_parameters()):
+        assert torch.equal(a, b), n
+    ckpt["_model.field.not_a_parameter"] = torch.zeros(1)  # anything else unexpected is still an error
+    with pytest.raises(RuntimeError, match="not_a_parameter"):
+        dst.load_state_dict(ckpt, strict=True)
+    direct = dict(src._model.state_dict())
+    direct["lpips.net.lin0.model.1.weight"] = torch.zeros(1, 64, 1, 1)
+    assert not dst._model.load_state_dict(direct, strict=True).unexpected_keys
